@@ -1,0 +1,92 @@
+"""ctypes binding of libdiffgraph_hip.so (the C ABI declared in include/diffgraph_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, a DiffGraphHipError is
+raised.  Tensors cross the boundary as raw device pointers (tensor.data_ptr()) plus sizes;
+the current torch HIP stream is passed as the stream argument.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffgraph_hip.so")
+
+DG_D = 64
+DG_MAX_TASKS = 8
+DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE = 1, 2, 4
+
+
+class DiffGraphHipError(RuntimeError):
+    pass
+
+
+class LayerTask(C.Structure):
+    _fields_ = [("graph", C.c_void_p), ("x", C.c_void_p), ("e_out", C.c_void_p), ("acc_in", C.c_void_p),
+                ("acc_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float)]
+
+
+class Denoiser(C.Structure):
+    _fields_ = [("w_emb", C.c_void_p), ("b_emb", C.c_void_p), ("w_in", C.c_void_p), ("b_in", C.c_void_p),
+                ("w_out", C.c_void_p), ("b_out", C.c_void_p), ("freqs_host", C.POINTER(C.c_float)),
+                ("norm", C.c_int32)]
+
+
+# name -> (restype, argtypes); one entry per symbol declared in include/diffgraph_hip.h
+SIGNATURES = {
+    "dg_version": (C.c_int, []),
+    "dg_last_error": (C.c_char_p, []),
+    "dg_graph_create": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                  C.POINTER(C.c_void_p)]),
+    "dg_graph_destroy": (None, [C.c_void_p]),
+    "dg_graph_num_nodes": (C.c_int32, [C.c_void_p]),
+    "dg_graph_num_edges": (C.c_int64, [C.c_void_p]),
+    "dg_graph_is_symmetric": (C.c_int, [C.c_void_p]),
+    "dg_graph_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "dg_spmm_norm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int,
+                                       C.c_void_p]),
+    "dg_gcn_layer_fwd": (C.c_int, [C.POINTER(LayerTask), C.c_int32, C.c_int32, C.c_void_p]),
+    "dg_sum_tables": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dg_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                              C.c_int32, C.c_void_p, C.c_void_p]),
+    "dg_time_bias_table": (C.c_int, [C.POINTER(Denoiser), C.c_int32, C.c_void_p, C.c_void_p]),
+    "dg_denoise_fwd": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_int32, C.c_void_p, C.c_void_p]),
+    "dg_p_sample_loop": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dg_diffusion_loss_fwd": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Loads the shared library (once) and types every exported entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DiffGraphHipError(
+            f"{LIB_PATH} not found: build it with `python -m diffgraph_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().dg_last_error()
+        raise DiffGraphHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr(device=None) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

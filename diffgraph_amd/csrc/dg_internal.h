@@ -1,0 +1,72 @@
+// Internal declarations shared by the translation units of libdiffgraph_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/diffgraph_hip.h"
+
+#define DG_ERR_ARG (-1)
+#define DG_ERR_DIM (-2)
+#define DG_ERR_SIZE (-3)
+
+// Records a printf-style message retrievable through dg_last_error(); returns `code`.
+int dg_fail(int code, const char *fmt, ...);
+
+#define DG_HIP(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return dg_fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// One direction of a graph: CSR over "rows" (the nodes that receive the sum) with the
+// degree-binned schedule the propagation kernel walks.
+struct dg_csr {
+  int32_t *rowptr = nullptr;     // [n+1]
+  int32_t *colidx = nullptr;     // [nnz], ascending inside a row
+  int32_t *row_order = nullptr;  // [n]: hub rows, then wave rows, then group rows (each by falling degree)
+  int32_t *hub_segptr = nullptr; // [n_hub+1] first slab row of each hub row (row_order order)
+  int32_t *seg_row = nullptr;    // [n_seg] hub ordinal of each segment
+  int32_t *seg_begin = nullptr;  // [n_seg] first colidx position of the segment
+  int32_t *seg_end = nullptr;    // [n_seg]
+  int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0;
+};
+
+struct dg_graph {
+  int32_t n = 0;
+  int64_t nnz = 0;
+  int symmetric = 0;
+  int32_t group_max = 0, seg_len = 0;
+  float *dinv_src = nullptr;  // [n] max(out_deg,1)^-1/2
+  float *dinv_dst = nullptr;  // [n] max(in_deg,1)^-1/2
+  dg_csr fwd;                 // rows = destinations, columns = sources
+  dg_csr bwd;                 // rows = sources, columns = destinations (aliases fwd when symmetric)
+  float *slab = nullptr;      // [max(fwd.n_seg,bwd.n_seg)][64] partial sums of hub-row segments
+  int device = 0;
+};
+
+// Device-visible description of one graph's share of a batched layer launch.
+struct dg_task_dev {
+  const int32_t *rowptr, *colidx, *row_order, *hub_segptr;
+  const int32_t *seg_row, *seg_begin, *seg_end;
+  const float *dinv_gather;  // norm of the gathered (column) node
+  const float *dinv_row;     // norm of the receiving (row) node
+  const float *dinv_out;     // norm applied by DG_OUT_PRESCALE (the row node's norm as a future source)
+  const float *x;
+  float *slab;
+  float *e_out;
+  const float *acc_in;
+  float *acc_out;
+  int32_t n, n_hub, n_wave, n_group, n_seg;
+  int32_t flags;
+  float slope;
+  int32_t blk_begin;      // first block of this task in the main launch
+  int32_t seg_blk_begin;  // first block of this task in the hub-partial launch
+};
+
+struct dg_task_batch {
+  dg_task_dev t[DG_MAX_TASKS];
+  int32_t n_tasks;
+};

@@ -1,0 +1,320 @@
+// Latent diffusion kernels for gfx950: q_sample, the timestep-conditioned denoiser MLP,
+// the SNR-weighted training loss and the T-step reverse (p_sample) loop.
+//
+// Replaces GaussianDiffusion.q_sample / p_sample / p_mean_variance / training_losses2
+// (DiffGraph-Rec/Model.py:287-366) and Denoise.forward (DiffGraph-Rec/Model.py:214-234).
+//
+// The denoiser is two 64x64 fp32 contractions per row (the 8 time-embedding columns of
+// in_layers[0] depend only on t and collapse into a per-timestep bias table).  They run on
+// the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 in TRANSPOSED orientation:
+//     H^T[out][row] = W[out][in] . X^T[in][row]
+// A wavefront owns 32 embedding rows.  The weight matrix is the A operand (read from an
+// LDS image laid out lane-linear, so the reads are conflict-free); the activations are the
+// B operand.  In this orientation the accumulator layout (row of the tile on the lane,
+// feature index  8*(r>>2) + 4*(lane>>5) + (r&3)  in register r) is exactly the B-operand
+// layout of the next contraction, so x, tanh(.) and the output never leave registers:
+// the whole 200-step reverse loop is one launch with no memory traffic inside the loop
+// beyond 256 B of bias per step.
+#include "dg_internal.h"
+
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kDnMaxTasks = 4;
+constexpr int kRowsPerWave = 32;
+constexpr int kWavesPerBlock = 4;
+constexpr int kRowsPerBlock = kRowsPerWave * kWavesPerBlock;
+constexpr int kThreads = kWavesPerBlock * 64;
+
+enum { MODE_FWD = 0, MODE_LOSS = 1, MODE_PSAMPLE = 2 };
+
+struct dn_task {
+  const float *w_in, *w_out, *b_out;
+  const float *time_bias;             // [n_steps][64]
+  const float *x;                     // FWD: x; LOSS: x_start; PSAMPLE: x_T
+  const float *noise, *target;        // LOSS
+  const int64_t *t;                   // FWD, LOSS: per-row timestep
+  const float *sqrt_ac, *sqrt_1mac;   // LOSS (NULL: x_t = x_start)
+  const float *coef1, *coef2;         // PSAMPLE
+  const double *loss_w;               // LOSS
+  float *out;
+  double *row_loss;
+  float *x_t_out;
+  int64_t n;
+  int32_t n_steps, norm, blk_begin;
+};
+
+struct dn_batch {
+  dn_task t[kDnMaxTasks];
+  int32_t n_tasks;
+};
+
+// Tile register r of lane half h holds feature 8*(r>>2) + 4*h + (r&3) of a 32-feature block;
+// the four registers 4q..4q+3 are the contiguous floats [8q+4h, 8q+4h+4).
+__device__ __forceinline__ void load_tile(const float *__restrict__ rowp, int h, bool valid, f32x16 (&v)[2]) {
+#pragma unroll
+  for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 f = {0.f, 0.f, 0.f, 0.f};
+      if (valid) f = *reinterpret_cast<const f32x4 *>(rowp + 32 * tau + 8 * q + 4 * h);
+      v[tau][4 * q + 0] = f.x; v[tau][4 * q + 1] = f.y; v[tau][4 * q + 2] = f.z; v[tau][4 * q + 3] = f.w;
+    }
+}
+
+__device__ __forceinline__ void store_tile(float *__restrict__ rowp, int h, bool valid, const f32x16 (&v)[2]) {
+  if (!valid) return;
+#pragma unroll
+  for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 f = {v[tau][4 * q + 0], v[tau][4 * q + 1], v[tau][4 * q + 2], v[tau][4 * q + 3]};
+      *reinterpret_cast<f32x4 *>(rowp + 32 * tau + 8 * q + 4 * h) = f;
+    }
+}
+
+// acc[to] += W[32*to .. +32][:] . act  for one 64x64 weight image in LDS.
+__device__ __forceinline__ void contract64(const f32x4 *__restrict__ wl, int lane, const f32x16 (&act)[2],
+                                           f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 a0 = wl[((0 * 2 + ti) * 4 + rq) * 64 + lane];
+      const f32x4 a1 = wl[((1 * 2 + ti) * 4 + rq) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], act[ti][4 * rq + e], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], act[ti][4 * rq + e], acc[1], 0, 0, 0);
+      }
+    }
+}
+
+// One Denoise.forward on the 32-row tile held in xs: F.normalize, in-layer + tanh, out-layer.
+__device__ __forceinline__ void denoise_tile(const f32x4 *__restrict__ wl, int lane, int h, bool norm,
+                                             const float *__restrict__ tb_row, const float *__restrict__ b_out,
+                                             const f32x16 (&xs)[2], f32x16 (&out)[2]) {
+  f32x16 xn[2] = {xs[0], xs[1]};
+  if (norm) {
+    float ss = 0.f;
+#pragma unroll
+    for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ss += xs[tau][r] * xs[tau][r];
+    ss += __shfl_xor(ss, 32);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    xn[0] = xs[0] * inv;
+    xn[1] = xs[1] * inv;
+  }
+  f32x16 hid[2];
+  load_tile(tb_row, h, true, hid);  // accumulator starts at b_in + W_in[:,64:72].emb(t)
+  contract64(wl, lane, xn, hid);
+#pragma unroll
+  for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[tau][r] = tanhf(hid[tau][r]);
+  load_tile(b_out, h, true, out);
+  contract64(wl + 2 * 2 * 4 * 64, lane, hid, out);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch batch) {
+  // [matrix][to][ti][rq][lane] float4: lane reads W[32*to + (lane&31)][32*ti + 8*rq + 4*(lane>>5) .. +4)
+  __shared__ f32x4 wl[2 * 2 * 2 * 4 * 64];
+  const int b = blockIdx.x;
+  int ti_ = 0;
+  for (int k = 1; k < batch.n_tasks; ++k)
+    if (b >= batch.t[k].blk_begin) ti_ = k;
+  const dn_task &T = batch.t[ti_];
+
+  for (int idx = threadIdx.x; idx < 2 * 2 * 2 * 4 * 64; idx += blockDim.x) {
+    const int ln = idx & 63, rq = (idx >> 6) & 3, ti = (idx >> 8) & 1, to = (idx >> 9) & 1, m = idx >> 10;
+    const int row = 32 * to + (ln & 31), col = 32 * ti + 8 * rq + 4 * (ln >> 5);
+    const float *src = m == 0 ? T.w_in + row * 72 + col : T.w_out + row * 64 + col;
+    wl[idx] = *reinterpret_cast<const f32x4 *>(src);
+  }
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int64_t row = ((int64_t)(b - T.blk_begin) * kWavesPerBlock + wave) * kRowsPerWave + j;
+  const bool valid = row < T.n;
+  const bool norm = T.norm != 0;
+
+  f32x16 xs[2], out[2];
+  load_tile(T.x + row * DG_D, h, valid, xs);
+
+  if (MODE == MODE_PSAMPLE) {
+    for (int step = T.n_steps - 1; step >= 0; --step) {
+      // Opaque copy of the lane id: keeps the compiler from hoisting the 128 weight
+      // registers out of the loop (that would halve the waves per SIMD).
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      denoise_tile(wl, ln, h, norm, T.time_bias + step * DG_D, T.b_out, xs, out);
+      const float c1 = T.coef1[step], c2 = T.coef2[step];
+      xs[0] = c1 * out[0] + c2 * xs[0];  // model_mean (Model.py:323)
+      xs[1] = c1 * out[1] + c2 * xs[1];
+    }
+    store_tile(T.out + row * DG_D, h, valid, xs);
+    return;
+  }
+
+  int t = 0;
+  if (valid) t = min(max((int)T.t[row], 0), T.n_steps - 1);  // callers validate; never index outside the tables
+  if (MODE == MODE_LOSS && T.sqrt_ac != nullptr) {  // q_sample (Model.py:302-305)
+    f32x16 nz[2];
+    load_tile(T.noise + row * DG_D, h, valid, nz);
+    const float a = T.sqrt_ac[t], s = T.sqrt_1mac[t];
+    xs[0] = a * xs[0] + s * nz[0];
+    xs[1] = a * xs[1] + s * nz[1];
+    if (T.x_t_out) store_tile(T.x_t_out + row * DG_D, h, valid, xs);
+  }
+  denoise_tile(wl, lane, h, norm, T.time_bias + t * DG_D, T.b_out, xs, out);
+  store_tile(T.out + row * DG_D, h, valid, out);
+  if (MODE == MODE_LOSS) {  // mean_flat((target-out)^2) * (SNR(t-1)-SNR(t)) (Model.py:360-364)
+    f32x16 tg[2];
+    load_tile(T.target + row * DG_D, h, valid, tg);
+    float ss = 0.f;
+#pragma unroll
+    for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float dlt = tg[tau][r] - out[tau][r];
+        ss += dlt * dlt;
+      }
+    ss += __shfl_xor(ss, 32);
+    if (valid && h == 0) T.row_loss[row] = T.loss_w[t] * (double)(ss * (1.0f / DG_D));
+  }
+}
+
+__global__ __launch_bounds__(256) void q_sample_kernel(const f32x4 *__restrict__ x0, const f32x4 *__restrict__ noise,
+                                                       const int64_t *__restrict__ t, const float *__restrict__ sa,
+                                                       const float *__restrict__ sb, f32x4 *__restrict__ xt, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ts = (int)t[i >> 4];
+    xt[i] = sa[ts] * x0[i] + sb[ts] * noise[i];
+  }
+}
+
+struct tb_args {
+  const float *w_emb, *b_emb, *w_in, *b_in;
+  float freqs[4];
+};
+
+// table[t][f] = b_in[f] + sum_e W_in[f][64+e] * (b_emb[e] + sum_k W_emb[e][k] * te_t[k]),
+// te_t = [cos(t*freqs), sin(t*freqs)]  (Model.py:215-220 and the last 8 input columns of :226-227).
+__global__ __launch_bounds__(64) void time_bias_kernel(tb_args a, float *__restrict__ table) {
+  const int t = blockIdx.x, f = threadIdx.x;
+  float te[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float arg = (float)t * a.freqs[k];
+    te[k] = cosf(arg);
+    te[k + 4] = sinf(arg);
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float emb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) emb += te[k] * a.w_emb[e * 8 + k];
+    emb += a.b_emb[e];
+    acc += emb * a.w_in[f * 72 + 64 + e];
+  }
+  table[t * DG_D + f] = acc + a.b_in[f];
+}
+
+int check_denoiser(const char *who, const dg_denoiser *dn, const float *time_bias, int32_t n_steps, int32_t d) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "%s: embedding width %d unsupported (built for %d)", who, d, DG_D);
+  if (!dn || !dn->w_in || !dn->w_out || !dn->b_out || !time_bias) return dg_fail(DG_ERR_ARG, "%s: NULL denoiser argument", who);
+  if (n_steps <= 0) return dg_fail(DG_ERR_ARG, "%s: n_steps must be positive", who);
+  if (((uintptr_t)dn->w_in | (uintptr_t)dn->w_out | (uintptr_t)dn->b_out | (uintptr_t)time_bias) & 15)
+    return dg_fail(DG_ERR_ARG, "%s: weight / table pointers must be 16-byte aligned", who);
+  return 0;
+}
+
+template <int MODE>
+int launch_one(dn_task &t, hipStream_t stream) {
+  if (t.n <= 0) return 0;
+  dn_batch batch;
+  t.blk_begin = 0;
+  for (int k = 0; k < kDnMaxTasks; ++k) batch.t[k] = t;
+  batch.n_tasks = 1;
+  const int64_t blocks = (t.n + kRowsPerBlock - 1) / kRowsPerBlock;
+  hipLaunchKernelGGL(denoise_kernel<MODE>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, batch);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dg_time_bias_table(const dg_denoiser *dn, int32_t n_steps, float *table, void *stream) {
+  if (!dn || !dn->w_emb || !dn->b_emb || !dn->w_in || !dn->b_in || !dn->freqs_host || !table)
+    return dg_fail(DG_ERR_ARG, "dg_time_bias_table: NULL argument");
+  if (n_steps <= 0) return dg_fail(DG_ERR_ARG, "dg_time_bias_table: n_steps must be positive");
+  tb_args a;
+  a.w_emb = dn->w_emb; a.b_emb = dn->b_emb; a.w_in = dn->w_in; a.b_in = dn->b_in;
+  for (int k = 0; k < 4; ++k) a.freqs[k] = dn->freqs_host[k];
+  hipLaunchKernelGGL(time_bias_kernel, dim3(n_steps), dim3(64), 0, (hipStream_t)stream, a, table);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dg_q_sample(const float *x0, const float *noise, const int64_t *t, const float *sqrt_ac,
+                           const float *sqrt_1mac, int32_t n_steps, int64_t n, int32_t d, float *x_t, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_q_sample: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!x0 || !noise || !t || !sqrt_ac || !sqrt_1mac || !x_t) return dg_fail(DG_ERR_ARG, "dg_q_sample: NULL argument");
+  if (n_steps <= 0 || n < 0) return dg_fail(DG_ERR_ARG, "dg_q_sample: bad sizes");
+  if (n == 0) return 0;
+  const int64_t n4 = n * (DG_D / 4);
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4 *>(x0), reinterpret_cast<const f32x4 *>(noise), t, sqrt_ac, sqrt_1mac,
+                     reinterpret_cast<f32x4 *>(x_t), n4);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dg_denoise_fwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps, const float *x,
+                              const int64_t *t, int64_t n, int32_t d, float *out, void *stream) {
+  int rc = check_denoiser("dg_denoise_fwd", dn, time_bias, n_steps, d);
+  if (rc) return rc;
+  if (!x || !t || !out || n < 0) return dg_fail(DG_ERR_ARG, "dg_denoise_fwd: NULL argument");
+  dn_task k = {};
+  k.w_in = dn->w_in; k.w_out = dn->w_out; k.b_out = dn->b_out; k.time_bias = time_bias;
+  k.x = x; k.t = t; k.out = out; k.n = n; k.n_steps = n_steps; k.norm = dn->norm;
+  return launch_one<MODE_FWD>(k, (hipStream_t)stream);
+}
+
+extern "C" int dg_p_sample_loop(const dg_denoiser *dn, const float *time_bias, const float *coef1, const float *coef2,
+                                int32_t n_steps, const float *x_T, int64_t n, int32_t d, float *x_0, void *stream) {
+  int rc = check_denoiser("dg_p_sample_loop", dn, time_bias, n_steps, d);
+  if (rc) return rc;
+  if (!coef1 || !coef2 || !x_T || !x_0 || n < 0) return dg_fail(DG_ERR_ARG, "dg_p_sample_loop: NULL argument");
+  dn_task k = {};
+  k.w_in = dn->w_in; k.w_out = dn->w_out; k.b_out = dn->b_out; k.time_bias = time_bias;
+  k.x = x_T; k.coef1 = coef1; k.coef2 = coef2; k.out = x_0; k.n = n; k.n_steps = n_steps; k.norm = dn->norm;
+  return launch_one<MODE_PSAMPLE>(k, (hipStream_t)stream);
+}
+
+extern "C" int dg_diffusion_loss_fwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps, const float *target,
+                                     const float *x_start, const float *noise, const int64_t *ts, const float *sqrt_ac,
+                                     const float *sqrt_1mac, const double *loss_w, int64_t n, int32_t d, float *out,
+                                     double *row_loss, float *x_t_out, void *stream) {
+  int rc = check_denoiser("dg_diffusion_loss_fwd", dn, time_bias, n_steps, d);
+  if (rc) return rc;
+  if (!target || !x_start || !ts || !loss_w || !out || !row_loss || n < 0)
+    return dg_fail(DG_ERR_ARG, "dg_diffusion_loss_fwd: NULL argument");
+  if ((sqrt_ac != nullptr) != (sqrt_1mac != nullptr) || (sqrt_ac && !noise))
+    return dg_fail(DG_ERR_ARG, "dg_diffusion_loss_fwd: sqrt_ac, sqrt_1mac and noise go together");
+  dn_task k = {};
+  k.w_in = dn->w_in; k.w_out = dn->w_out; k.b_out = dn->b_out; k.time_bias = time_bias;
+  k.x = x_start; k.noise = noise; k.target = target; k.t = ts; k.sqrt_ac = sqrt_ac; k.sqrt_1mac = sqrt_1mac;
+  k.loss_w = loss_w; k.out = out; k.row_loss = row_loss; k.x_t_out = x_t_out; k.n = n; k.n_steps = n_steps;
+  k.norm = dn->norm;
+  return launch_one<MODE_LOSS>(k, (hipStream_t)stream);
+}

@@ -1,0 +1,218 @@
+// Graph handle: host-side CSR construction, degree norms and the degree-binned row schedule.
+//
+// Stands in for the dgl.DGLGraph the reference builds with dgl.graph((src,dst), num_nodes)
+// (DiffGraph-Rec/DataHandler.py:120-132) and for graph.out_degrees()/in_degrees() +
+// clamp(min=1) + pow(-0.5), which the reference recomputes on every layer call
+// (DiffGraph-Rec/Model.py:151-152,165-166) and this handle computes once.
+#include "dg_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+
+int dg_fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+extern "C" const char *dg_last_error(void) { return g_last_error.c_str(); }
+extern "C" int dg_version(void) { return 1; }
+
+namespace {
+
+struct HostCsr {
+  std::vector<int32_t> rowptr, colidx, row_order, hub_segptr, seg_row, seg_begin, seg_end;
+  int32_t n_hub = 0, n_wave = 0, n_group = 0;
+};
+
+// CSR over `row` with ascending `col` inside each row: two stable counting sorts
+// (by col, then by row), O(n + nnz).
+void build_csr(int32_t n, int64_t nnz, const int32_t *row, const int32_t *col, HostCsr &out) {
+  std::vector<int64_t> cnt((size_t)n + 1, 0);
+  for (int64_t e = 0; e < nnz; ++e) cnt[(size_t)col[e] + 1]++;
+  for (int32_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+  std::vector<int32_t> by_col((size_t)nnz);
+  {
+    std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+    for (int64_t e = 0; e < nnz; ++e) by_col[(size_t)pos[col[e]]++] = (int32_t)e;
+  }
+  out.rowptr.assign((size_t)n + 1, 0);
+  std::vector<int64_t> rp((size_t)n + 1, 0);
+  for (int64_t e = 0; e < nnz; ++e) rp[(size_t)row[e] + 1]++;
+  for (int32_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
+  out.colidx.resize((size_t)nnz);
+  {
+    std::vector<int64_t> pos(rp.begin(), rp.end() - 1);
+    for (int64_t k = 0; k < nnz; ++k) {
+      int32_t e = by_col[(size_t)k];
+      out.colidx[(size_t)pos[row[e]]++] = col[e];
+    }
+  }
+  for (int32_t i = 0; i <= n; ++i) out.rowptr[i] = (int32_t)rp[i];
+}
+
+// Rows ordered hub | wave | group, each class by falling degree (ties: rising row id), so
+// the longest work starts first and the four rows sharing a wavefront have like lengths.
+void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c) {
+  std::vector<int32_t> deg(n);
+  for (int32_t i = 0; i < n; ++i) deg[i] = c.rowptr[i + 1] - c.rowptr[i];
+  c.row_order.resize(n);
+  std::iota(c.row_order.begin(), c.row_order.end(), 0);
+  std::stable_sort(c.row_order.begin(), c.row_order.end(),
+                   [&](int32_t a, int32_t b) { return deg[a] > deg[b]; });
+  c.n_hub = c.n_wave = c.n_group = 0;
+  for (int32_t k = 0; k < n; ++k) {
+    int32_t d = deg[c.row_order[k]];
+    if (d > seg_len) c.n_hub++;
+    else if (d > group_max) c.n_wave++;
+    else c.n_group++;
+  }
+  c.hub_segptr.assign((size_t)c.n_hub + 1, 0);
+  c.seg_row.clear(); c.seg_begin.clear(); c.seg_end.clear();
+  for (int32_t h = 0; h < c.n_hub; ++h) {
+    int32_t r = c.row_order[h];
+    int32_t b = c.rowptr[r], e = c.rowptr[r + 1];
+    for (int32_t p = b; p < e; p += seg_len) {
+      c.seg_row.push_back(h);
+      c.seg_begin.push_back(p);
+      c.seg_end.push_back(std::min(p + seg_len, e));
+    }
+    c.hub_segptr[h + 1] = (int32_t)c.seg_row.size();
+  }
+}
+
+template <class T>
+hipError_t upload(const std::vector<T> &v, T **dst) {
+  *dst = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  hipError_t e = hipMalloc((void **)dst, bytes);
+  if (e != hipSuccess) return e;
+  if (!v.empty()) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  return e;
+}
+
+hipError_t upload_csr(const HostCsr &h, dg_csr &d) {
+  hipError_t e;
+  if ((e = upload(h.rowptr, &d.rowptr)) != hipSuccess) return e;
+  if ((e = upload(h.colidx, &d.colidx)) != hipSuccess) return e;
+  if ((e = upload(h.row_order, &d.row_order)) != hipSuccess) return e;
+  if ((e = upload(h.hub_segptr, &d.hub_segptr)) != hipSuccess) return e;
+  if ((e = upload(h.seg_row, &d.seg_row)) != hipSuccess) return e;
+  if ((e = upload(h.seg_begin, &d.seg_begin)) != hipSuccess) return e;
+  if ((e = upload(h.seg_end, &d.seg_end)) != hipSuccess) return e;
+  d.n_hub = h.n_hub; d.n_wave = h.n_wave; d.n_group = h.n_group;
+  d.n_seg = (int32_t)h.seg_row.size();
+  return hipSuccess;
+}
+
+void free_csr(dg_csr &d) {
+  (void)hipFree(d.rowptr); (void)hipFree(d.colidx); (void)hipFree(d.row_order); (void)hipFree(d.hub_segptr);
+  (void)hipFree(d.seg_row); (void)hipFree(d.seg_begin); (void)hipFree(d.seg_end);
+  d = dg_csr();
+}
+
+}  // namespace
+
+extern "C" int dg_graph_create(int32_t n, int64_t nnz, const int32_t *src, const int32_t *dst,
+                               int32_t group_max, int32_t seg_len, dg_graph **out) {
+  if (!out) return dg_fail(DG_ERR_ARG, "dg_graph_create: out is NULL");
+  *out = nullptr;
+  if (n <= 0) return dg_fail(DG_ERR_ARG, "dg_graph_create: n_nodes must be positive (got %d)", n);
+  if (nnz < 0 || (nnz > 0 && (!src || !dst)))
+    return dg_fail(DG_ERR_ARG, "dg_graph_create: bad edge arrays");
+  if (nnz >= (int64_t)INT32_MAX)
+    return dg_fail(DG_ERR_SIZE, "dg_graph_create: %lld edges exceed the int32 CSR limit", (long long)nnz);
+  if ((int64_t)n * DG_D * 4 >= ((int64_t)1 << 32))
+    return dg_fail(DG_ERR_SIZE, "dg_graph_create: %d nodes exceed the 4 GiB table limit of the gather path", n);
+  if (group_max <= 0) group_max = 32;
+  if (seg_len <= 0) seg_len = 256;
+  if (seg_len < 64 || seg_len % 64 != 0)
+    return dg_fail(DG_ERR_ARG, "dg_graph_create: seg_len must be a positive multiple of 64 (got %d)", seg_len);
+  if (group_max > seg_len) group_max = seg_len;
+  for (int64_t e = 0; e < nnz; ++e)
+    if (src[e] < 0 || src[e] >= n || dst[e] < 0 || dst[e] >= n)
+      return dg_fail(DG_ERR_ARG, "dg_graph_create: edge %lld (%d -> %d) out of range [0,%d)", (long long)e, src[e], dst[e], n);
+
+  HostCsr f, b;
+  build_csr(n, nnz, dst, src, f);  // rows = destinations
+  build_csr(n, nnz, src, dst, b);  // rows = sources
+  const bool symmetric = (f.rowptr == b.rowptr) && (f.colidx == b.colidx);
+  build_schedule(n, group_max, seg_len, f);
+  if (!symmetric) build_schedule(n, group_max, seg_len, b);
+
+  // clamp(min=1), pow(-0.5) in fp32: torch's CPU path evaluates pow(x,-0.5) as 1/sqrt(x)
+  // with correctly rounded sqrt and divide, which is what this does.
+  std::vector<float> dsrc(n), ddst(n);
+  for (int32_t i = 0; i < n; ++i) {
+    int32_t in_deg = f.rowptr[i + 1] - f.rowptr[i];
+    int32_t out_deg = b.rowptr[i + 1] - b.rowptr[i];
+    ddst[i] = 1.0f / sqrtf((float)std::max(in_deg, 1));
+    dsrc[i] = 1.0f / sqrtf((float)std::max(out_deg, 1));
+  }
+
+  dg_graph *g = new dg_graph();
+  g->n = n; g->nnz = nnz; g->symmetric = symmetric ? 1 : 0;
+  g->group_max = group_max; g->seg_len = seg_len;
+  hipError_t e = hipGetDevice(&g->device);
+  if (e == hipSuccess) e = upload(dsrc, &g->dinv_src);
+  if (e == hipSuccess) e = upload(ddst, &g->dinv_dst);
+  if (e == hipSuccess) e = upload_csr(f, g->fwd);
+  if (e == hipSuccess) {
+    if (symmetric) g->bwd = g->fwd;
+    else e = upload_csr(b, g->bwd);
+  }
+  if (e == hipSuccess) {
+    size_t segs = (size_t)std::max(g->fwd.n_seg, g->bwd.n_seg);
+    e = hipMalloc((void **)&g->slab, std::max<size_t>(segs, 1) * DG_D * sizeof(float));
+  }
+  if (e != hipSuccess) {
+    dg_graph_destroy(g);
+    return dg_fail((int)e, "dg_graph_create: device allocation/copy failed: %s", hipGetErrorString(e));
+  }
+  *out = g;
+  return 0;
+}
+
+extern "C" void dg_graph_destroy(dg_graph *g) {
+  if (!g) return;
+  if (!g->symmetric) free_csr(g->bwd);
+  free_csr(g->fwd);
+  (void)hipFree(g->dinv_src); (void)hipFree(g->dinv_dst); (void)hipFree(g->slab);
+  delete g;
+}
+
+extern "C" int32_t dg_graph_num_nodes(const dg_graph *g) { return g ? g->n : 0; }
+extern "C" int64_t dg_graph_num_edges(const dg_graph *g) { return g ? g->nnz : 0; }
+extern "C" int dg_graph_is_symmetric(const dg_graph *g) { return g ? g->symmetric : 0; }
+
+extern "C" int dg_graph_export(const dg_graph *g, int which, void *dst, size_t bytes) {
+  if (!g || !dst) return dg_fail(DG_ERR_ARG, "dg_graph_export: NULL argument");
+  const void *src = nullptr;
+  size_t need = 0;
+  int32_t counts[4] = {g->fwd.n_hub, g->fwd.n_wave, g->fwd.n_group, g->fwd.n_seg};
+  switch (which) {
+    case 0: src = g->fwd.rowptr; need = ((size_t)g->n + 1) * 4; break;
+    case 1: src = g->fwd.colidx; need = (size_t)g->nnz * 4; break;
+    case 2: src = g->dinv_src; need = (size_t)g->n * 4; break;
+    case 3: src = g->dinv_dst; need = (size_t)g->n * 4; break;
+    case 4: src = g->fwd.row_order; need = (size_t)g->n * 4; break;
+    case 5:
+      if (bytes < sizeof(counts)) return dg_fail(DG_ERR_SIZE, "dg_graph_export: buffer too small");
+      memcpy(dst, counts, sizeof(counts));
+      return 0;
+    default: return dg_fail(DG_ERR_ARG, "dg_graph_export: unknown selector %d", which);
+  }
+  if (bytes < need) return dg_fail(DG_ERR_SIZE, "dg_graph_export: buffer too small (%zu < %zu)", bytes, need);
+  if (need) DG_HIP(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
+  return 0;
+}

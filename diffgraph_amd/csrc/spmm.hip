@@ -1,0 +1,290 @@
+// Normalised-adjacency propagation for gfx950: CSR row gather with a fused
+// LeakyReLU / row-L2-normalise / layer-sum epilogue.
+//
+// Replaces, per call, the chain  cat -> out_degrees/pow -> scale -> update_all(copy_u,sum)
+// -> in_degrees/pow -> scale -> LeakyReLU  of DGLLayer.forward (DiffGraph-Rec/Model.py:142-174)
+// and UUGCNLayer.forward (DiffGraph_NC/Model.py:184-214), plus F.normalize and the running
+// layer sum of HGDM.forward (DiffGraph-Rec/Model.py:67-70,81-84).
+//
+// Mapping.  An embedding row is 64 fp32 = 256 B.  A row is owned by a GROUP of 16 lanes,
+// each lane holding one float4 of it, so one wavefront load instruction gathers four whole
+// neighbour rows (1 KiB, four fully used 256-B segments).  A group reads 16 neighbour ids
+// with one coalesced load, then hands them round with DPP row broadcasts (no LDS).  Rows
+// are binned by in-degree on the host:
+//   group rows (deg <= group_max): one group per row, four rows per wavefront;
+//   wave rows  (deg <= seg_len)  : the four groups of a wavefront take every fourth chunk
+//                                  of 16 neighbours, then add their sums;
+//   hub rows   (deg >  seg_len)  : cut into seg_len-neighbour segments summed by separate
+//                                  wavefronts into a slab (first launch); the row's own
+//                                  wavefront then adds the slab rows in order.
+// Every sum has a fixed order, so results are bitwise reproducible run to run.
+// Neighbour gathers go through a buffer descriptor: the id -1 of a padding slot turns
+// into an out-of-range offset, which the hardware answers with zeros and no memory access.
+#include "dg_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int K>
+__device__ __forceinline__ int bcast16(int v) {
+  // lane K of each row of 16 lanes -> every lane of that row
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, false);
+}
+template <int K>
+__device__ __forceinline__ float bcast16f(float v) {
+  return __builtin_bit_cast(float, bcast16<K>(__builtin_bit_cast(int, v)));
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const float *base, int32_t rows) {
+  return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, rows * (DG_D * 4), 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 load_row16(__amdgpu_buffer_rsrc_t r, int row, unsigned lane_off) {
+  unsigned off = (unsigned)row * (unsigned)(DG_D * 4) + lane_off;  // row == -1 -> out of range -> zeros
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// Four neighbours K0..K0+3 of the current chunk: issue the four row loads, then add.
+template <int K0, bool SCALE>
+__device__ __forceinline__ void gather4(__amdgpu_buffer_rsrc_t xr, int c, float s, unsigned lane_off, f32x4 &acc) {
+  const int c0 = bcast16<K0>(c), c1 = bcast16<K0 + 1>(c), c2 = bcast16<K0 + 2>(c), c3 = bcast16<K0 + 3>(c);
+  f32x4 v0 = load_row16(xr, c0, lane_off);
+  f32x4 v1 = load_row16(xr, c1, lane_off);
+  f32x4 v2 = load_row16(xr, c2, lane_off);
+  f32x4 v3 = load_row16(xr, c3, lane_off);
+  if (SCALE) {  // node_f * norm, rounded, before the sum (Model.py:157)
+    v0 *= bcast16f<K0>(s); v1 *= bcast16f<K0 + 1>(s); v2 *= bcast16f<K0 + 2>(s); v3 *= bcast16f<K0 + 3>(s);
+  }
+  acc += v0; acc += v1; acc += v2; acc += v3;
+}
+
+// Sum of the table rows listed in colidx[p .. end) taken 16 at a time with stride `stride`
+// between chunks (16: the group owns the whole list; 64: four groups interleave).
+// INDEXED = false reads rows p, p+1, ... themselves (slab rows of a hub row).
+template <bool INDEXED, bool SCALE>
+__device__ __forceinline__ f32x4 gather_rows(__amdgpu_buffer_rsrc_t xr, const int32_t *__restrict__ colidx,
+                                             const float *__restrict__ dinv, int p, int end, int stride, int l) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const unsigned lane_off = (unsigned)l * 16u;
+  int c = -1;
+  float s = 0.f;
+  if (p + l < end) {
+    c = INDEXED ? colidx[p + l] : p + l;
+    if (SCALE) s = dinv[c];
+  }
+  while (p < end) {
+    const int pn = p + stride;
+    int cn = -1;
+    float sn = 0.f;
+    if (pn + l < end) {  // next chunk's ids (and norms) are in flight while this chunk's rows load
+      cn = INDEXED ? colidx[pn + l] : pn + l;
+      if (SCALE) sn = dinv[cn];
+    }
+    const int cnt = end - p;
+    gather4<0, SCALE>(xr, c, s, lane_off, acc);
+    if (cnt > 4) gather4<4, SCALE>(xr, c, s, lane_off, acc);
+    if (cnt > 8) gather4<8, SCALE>(xr, c, s, lane_off, acc);
+    if (cnt > 12) gather4<12, SCALE>(xr, c, s, lane_off, acc);
+    c = cn; s = sn; p = pn;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ f32x4 add_groups(f32x4 v) {  // (g0+g1)+(g2+g3), same value in every group
+  f32x4 o;
+  o.x = __shfl_xor(v.x, 16); o.y = __shfl_xor(v.y, 16); o.z = __shfl_xor(v.z, 16); o.w = __shfl_xor(v.w, 16);
+  v += o;
+  o.x = __shfl_xor(v.x, 32); o.y = __shfl_xor(v.y, 32); o.z = __shfl_xor(v.z, 32); o.w = __shfl_xor(v.w, 32);
+  return v + o;
+}
+
+__device__ __forceinline__ float sum16(float v) {
+  v += __shfl_xor(v, 8, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 1, 16);
+  return v;
+}
+
+// rst*norm, LeakyReLU, F.normalize, layer sum, next layer's input (Model.py:165-172,67-70).
+__device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, f32x4 acc, int l) {
+  const float di = T.dinv_row[row];
+  const float slope = T.slope;
+  f32x4 y = acc * di;
+  y.x = y.x > 0.f ? y.x : y.x * slope;
+  y.y = y.y > 0.f ? y.y : y.y * slope;
+  y.z = y.z > 0.f ? y.z : y.z * slope;
+  y.w = y.w > 0.f ? y.w : y.w * slope;
+  const size_t o = (size_t)row * (DG_D / 4) + l;
+  const bool want_norm = (T.acc_out != nullptr) || (T.flags & DG_OUT_NORM);
+  f32x4 yn = y;
+  if (want_norm) {
+    float ss = sum16(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
+    const float den = fmaxf(sqrtf(ss), 1e-12f);
+    yn = y / den;
+  }
+  if (T.acc_out) {
+    f32x4 a = reinterpret_cast<const f32x4 *>(T.acc_in)[o];
+    reinterpret_cast<f32x4 *>(T.acc_out)[o] = a + yn;
+  }
+  if (T.e_out) {
+    f32x4 e = (T.flags & DG_OUT_NORM) ? yn : y;
+    if (T.flags & DG_OUT_PRESCALE) e *= T.dinv_out[row];
+    reinterpret_cast<f32x4 *>(T.e_out)[o] = e;
+  }
+}
+
+template <bool SCALE>
+__device__ __forceinline__ void layer_block(const dg_task_dev &T, int lb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l = lane & 15;
+  const int nb_hub = (T.n_hub + 3) >> 2, nb_wave = (T.n_wave + 3) >> 2;
+  if (lb < nb_hub) {
+    const int h = lb * 4 + wave;
+    if (h < T.n_hub) {
+      const int row = T.row_order[h];
+      const int s0 = T.hub_segptr[h], s1 = T.hub_segptr[h + 1];
+      f32x4 acc = gather_rows<false, false>(table_rsrc(T.slab, T.n_seg), nullptr, nullptr, s0 + 16 * q, s1, 64, l);
+      acc = add_groups(acc);
+      if (q == 0) epilogue(T, row, acc, l);
+    }
+  } else if (lb < nb_hub + nb_wave) {
+    const int k = (lb - nb_hub) * 4 + wave;
+    if (k < T.n_wave) {
+      const int row = T.row_order[T.n_hub + k];
+      const int b = T.rowptr[row], e = T.rowptr[row + 1];
+      f32x4 acc = gather_rows<true, SCALE>(table_rsrc(T.x, T.n), T.colidx, T.dinv_gather, b + 16 * q, e, 64, l);
+      acc = add_groups(acc);
+      if (q == 0) epilogue(T, row, acc, l);
+    }
+  } else {
+    const int k = (lb - nb_hub - nb_wave) * 16 + wave * 4 + q;
+    if (k < T.n_group) {
+      const int row = T.row_order[T.n_hub + T.n_wave + k];
+      const int b = T.rowptr[row], e = T.rowptr[row + 1];
+      f32x4 acc = gather_rows<true, SCALE>(table_rsrc(T.x, T.n), T.colidx, T.dinv_gather, b, e, 16, l);
+      epilogue(T, row, acc, l);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gcn_layer_kernel(const dg_task_batch batch) {
+  const int b = blockIdx.x;
+  int ti = 0;
+  for (int k = 1; k < batch.n_tasks; ++k)
+    if (b >= batch.t[k].blk_begin) ti = k;
+  const dg_task_dev &T = batch.t[ti];
+  if (T.flags & DG_IN_PRESCALED) layer_block<false>(T, b - T.blk_begin);
+  else layer_block<true>(T, b - T.blk_begin);
+}
+
+// Partial sums of hub-row segments: one wavefront per segment -> slab[segment][64].
+__global__ __launch_bounds__(256) void hub_partial_kernel(const dg_task_batch batch) {
+  const int b = blockIdx.x;
+  int ti = 0;
+  for (int k = 1; k < batch.n_tasks; ++k)
+    if (b >= batch.t[k].seg_blk_begin) ti = k;
+  const dg_task_dev &T = batch.t[ti];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l = lane & 15;
+  const int s = (b - T.seg_blk_begin) * 4 + wave;
+  if (s >= T.n_seg) return;
+  const int p = T.seg_begin[s], e = T.seg_end[s];
+  f32x4 acc;
+  if (T.flags & DG_IN_PRESCALED)
+    acc = gather_rows<true, false>(table_rsrc(T.x, T.n), T.colidx, T.dinv_gather, p + 16 * q, e, 64, l);
+  else
+    acc = gather_rows<true, true>(table_rsrc(T.x, T.n), T.colidx, T.dinv_gather, p + 16 * q, e, 64, l);
+  acc = add_groups(acc);
+  if (q == 0) reinterpret_cast<f32x4 *>(T.slab)[(size_t)s * (DG_D / 4) + l] = acc;
+}
+
+struct sum_args {
+  const float *in[8];
+  int32_t n_in;
+};
+
+__global__ __launch_bounds__(256) void sum_tables_kernel(sum_args a, f32x4 *__restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 v = reinterpret_cast<const f32x4 *>(a.in[0])[i];
+    for (int k = 1; k < a.n_in; ++k) v += reinterpret_cast<const f32x4 *>(a.in[k])[i];
+    out[i] = v;
+  }
+}
+
+int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
+  const dg_graph *g = in.graph;
+  if (!g) return dg_fail(DG_ERR_ARG, "layer task: graph is NULL");
+  if (!in.x) return dg_fail(DG_ERR_ARG, "layer task: x is NULL");
+  if ((in.acc_out != nullptr) != (in.acc_in != nullptr))
+    return dg_fail(DG_ERR_ARG, "layer task: acc_in and acc_out must both be set or both be NULL");
+  if (!in.e_out && !in.acc_out) return dg_fail(DG_ERR_ARG, "layer task: no output requested");
+  if (in.e_out == in.x) return dg_fail(DG_ERR_ARG, "layer task: e_out must not alias x");
+  const dg_csr &c = transpose ? g->bwd : g->fwd;
+  o.rowptr = c.rowptr; o.colidx = c.colidx; o.row_order = c.row_order; o.hub_segptr = c.hub_segptr;
+  o.seg_row = c.seg_row; o.seg_begin = c.seg_begin; o.seg_end = c.seg_end;
+  o.dinv_gather = transpose ? g->dinv_dst : g->dinv_src;
+  o.dinv_row = transpose ? g->dinv_src : g->dinv_dst;
+  o.dinv_out = o.dinv_gather;
+  o.x = in.x; o.slab = g->slab; o.e_out = in.e_out; o.acc_in = in.acc_in; o.acc_out = in.acc_out;
+  o.n = g->n; o.n_hub = c.n_hub; o.n_wave = c.n_wave; o.n_group = c.n_group; o.n_seg = c.n_seg;
+  o.flags = in.flags; o.slope = in.slope;
+  return 0;
+}
+
+int launch_layer(const dg_layer_task *tasks, int32_t n_tasks, int transpose, hipStream_t stream) {
+  dg_task_batch batch;
+  batch.n_tasks = n_tasks;
+  int32_t blocks = 0, seg_blocks = 0;
+  for (int k = 0; k < n_tasks; ++k) {
+    int rc = fill_task(tasks[k], transpose, batch.t[k]);
+    if (rc) return rc;
+    for (int j = 0; j < k; ++j)
+      if (tasks[j].graph == tasks[k].graph && batch.t[k].n_seg > 0)
+        return dg_fail(DG_ERR_ARG, "layer tasks %d and %d share a graph with hub rows (one slab per graph)", j, k);
+    dg_task_dev &t = batch.t[k];
+    t.blk_begin = blocks;
+    t.seg_blk_begin = seg_blocks;
+    blocks += ((t.n_hub + 3) >> 2) + ((t.n_wave + 3) >> 2) + ((t.n_group + 15) >> 4);
+    seg_blocks += (t.n_seg + 3) >> 2;
+  }
+  for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
+  if (seg_blocks > 0) hipLaunchKernelGGL(hub_partial_kernel, dim3(seg_blocks), dim3(256), 0, stream, batch);
+  if (blocks > 0) hipLaunchKernelGGL(gcn_layer_kernel, dim3(blocks), dim3(256), 0, stream, batch);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dg_gcn_layer_fwd(const dg_layer_task *tasks, int32_t n_tasks, int32_t d, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_gcn_layer_fwd: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!tasks || n_tasks <= 0 || n_tasks > DG_MAX_TASKS)
+    return dg_fail(DG_ERR_ARG, "dg_gcn_layer_fwd: n_tasks must be in [1,%d] (got %d)", DG_MAX_TASKS, n_tasks);
+  return launch_layer(tasks, n_tasks, 0, (hipStream_t)stream);
+}
+
+extern "C" int dg_spmm_norm_act_fwd(dg_graph *g, const float *x, float *y, int32_t d, float slope, int transpose,
+                                    void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_spmm_norm_act_fwd: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!g || !x || !y) return dg_fail(DG_ERR_ARG, "dg_spmm_norm_act_fwd: NULL argument");
+  dg_layer_task t;
+  t.graph = g; t.x = x; t.e_out = y; t.acc_in = nullptr; t.acc_out = nullptr; t.flags = 0; t.slope = slope;
+  return launch_layer(&t, 1, transpose, (hipStream_t)stream);
+}
+
+extern "C" int dg_sum_tables(const float *const *in, int32_t n_in, float *out, int64_t n_elems, void *stream) {
+  if (!in || !out || n_in < 1 || n_in > 8) return dg_fail(DG_ERR_ARG, "dg_sum_tables: n_in must be in [1,8]");
+  if (n_elems % 4 != 0) return dg_fail(DG_ERR_ARG, "dg_sum_tables: element count must be a multiple of 4");
+  sum_args a;
+  a.n_in = n_in;
+  for (int k = 0; k < 8; ++k) a.in[k] = in[k < n_in ? k : 0];
+  const int64_t n4 = n_elems / 4;
+  if (n4 == 0) return 0;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sum_tables_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a,
+                     reinterpret_cast<f32x4 *>(out), n4);
+  DG_HIP(hipGetLastError());
+  return 0;
+}

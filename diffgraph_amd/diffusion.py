@@ -1,0 +1,189 @@
+"""GaussianDiffusion and Denoise with the reference's method signatures
+(DiffGraph-Rec/Model.py:176-399; DiffGraph_NC/Model.py:217-415 is the same code minus
+importance sampling), driving the HIP kernels.
+
+Differences a caller can see:
+  * training_losses2 / q_sample / p_sample accept optional `ts` / `noise` tensors so runs
+    are reproducible; left as None they are drawn with torch like the reference does.
+  * The noise-schedule tables are built in fp64 on the host with the reference's torch ops,
+    then cast to fp32 device tables once (the reference indexes the fp64 table and casts
+    the gathered values, which gives the same fp32 numbers).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from ._lib import DG_D, DiffGraphHipError
+
+
+class Denoise(nn.Module):
+    """Denoise(in_dims, out_dims, emb_size, norm, dropout) -- Model.py:176-234."""
+
+    def __init__(self, in_dims, out_dims, emb_size, norm=False, dropout=0.5):
+        super().__init__()
+        if list(in_dims) != [DG_D, DG_D] or list(out_dims) != [DG_D, DG_D] or emb_size != 8:
+            raise NotImplementedError("kernels are built for dims='[64]', latdim=64, d_emb_size=8 (the reference defaults)")
+        self.in_dims, self.out_dims = in_dims, out_dims
+        self.time_emb_dim = emb_size
+        self.norm = norm
+        self.emb_layer = nn.Linear(emb_size, emb_size)
+        self.in_layers = nn.ModuleList([nn.Linear(DG_D + emb_size, DG_D)])
+        self.out_layers = nn.ModuleList([nn.Linear(DG_D, DG_D)])
+        self.drop = nn.Dropout(dropout)
+        self.init_weights()
+        self._params = {}
+
+    def init_weights(self):  # Model.py:196-212
+        for layer in list(self.in_layers) + list(self.out_layers) + [self.emb_layer]:
+            size = layer.weight.size()
+            std = np.sqrt(2.0 / (size[0] + size[1]))
+            layer.weight.data.normal_(0.0, std)
+            layer.bias.data.normal_(0.0, 0.001)
+
+    def params(self, norm: bool) -> ops.DenoiserParams:
+        """Kernel-side view of the weights (pointers stay valid across in-place optimiser steps)."""
+        ws = (self.emb_layer.weight, self.emb_layer.bias, self.in_layers[0].weight, self.in_layers[0].bias,
+              self.out_layers[0].weight, self.out_layers[0].bias)
+        key = (bool(norm),) + tuple(w.data_ptr() for w in ws)
+        p = self._params.get(key)
+        if p is None:
+            self._params.clear()
+            p = ops.DenoiserParams(*[w.data for w in ws], norm=norm)
+            self._params[key] = p
+        return p
+
+    def forward(self, x, timesteps, mess_dropout=True):
+        n_steps = int(getattr(self, "n_steps", 0)) or int(timesteps.max().item()) + 1
+        norm = bool(self.norm)
+        if mess_dropout and self.training and self.drop.p > 0:
+            # dropout sits between F.normalize and the first Linear (Model.py:221-224)
+            if norm:
+                x = F.normalize(x)
+            x = self.drop(x)
+            norm = False
+        p = self.params(norm)
+        p.time_bias(n_steps, refresh=True)
+        return ops.denoise_fwd(p, x.contiguous(), timesteps, n_steps)
+
+
+class GaussianDiffusion(nn.Module):
+    """GaussianDiffusion(noise_scale, noise_min, noise_max, steps) -- Model.py:236-399."""
+
+    def __init__(self, noise_scale, noise_min, noise_max, steps, beta_fixed=True):
+        super().__init__()
+        self.noise_scale, self.noise_min, self.noise_max, self.steps = noise_scale, noise_min, noise_max, steps
+        self._dev_tables = {}
+        if noise_scale != 0:
+            self.betas = torch.tensor(self.get_betas(), dtype=torch.float64)
+            if beta_fixed:
+                self.betas[0] = 0.0001
+            self.calculate_for_diffusion()
+
+    def get_betas(self):  # Model.py:257-266
+        start = self.noise_scale * self.noise_min
+        end = self.noise_scale * self.noise_max
+        variance = np.linspace(start, end, self.steps, dtype=np.float64)
+        alpha_bar = 1 - variance
+        betas = [1 - alpha_bar[0]]
+        for i in range(1, self.steps):
+            betas.append(min(1 - alpha_bar[i] / alpha_bar[i - 1], 0.999))
+        return np.array(betas)
+
+    def calculate_for_diffusion(self):  # Model.py:268-285
+        alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = torch.cat([torch.tensor([1.0], dtype=torch.float64), self.alphas_cumprod[:-1]])
+        self.alphas_cumprod_next = torch.cat([self.alphas_cumprod[1:], torch.tensor([0.0], dtype=torch.float64)])
+        self.sqrt_alphas_cumprod = torch.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = torch.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = torch.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = self.betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = torch.log(
+            torch.cat([self.posterior_variance[1].unsqueeze(0), self.posterior_variance[1:]]))
+        self.posterior_mean_coef1 = self.betas * torch.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * torch.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        # SNR(t-1) - SNR(t), 1.0 at t == 0 (Model.py:362-363), fp64
+        snr = self.alphas_cumprod / (1 - self.alphas_cumprod)
+        w = torch.roll(snr, 1) - snr
+        w[0] = 1.0
+        self.loss_weight = w
+
+    # -- device copies ----------------------------------------------------------------
+    def _dev(self, name: str, device, dtype=torch.float32) -> torch.Tensor:
+        key = (name, str(device), dtype)
+        t = self._dev_tables.get(key)
+        if t is None:
+            t = getattr(self, name).to(dtype).to(device).contiguous()
+            self._dev_tables[key] = t
+        return t
+
+    # -- reference API ------------------------------------------------------------------
+    def _extract_into_tensor(self, arr, timesteps, broadcast_shape):  # Model.py:307-312
+        res = arr.to(timesteps.device)[timesteps].float()
+        while len(res.shape) < len(broadcast_shape):
+            res = res[..., None]
+        return res.expand(broadcast_shape)
+
+    def q_sample(self, x_start, t, noise=None):  # Model.py:302-305
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        dev = x_start.device
+        return ops.q_sample(x_start.contiguous(), noise.contiguous(), t, self._dev("sqrt_alphas_cumprod", dev),
+                            self._dev("sqrt_one_minus_alphas_cumprod", dev))
+
+    def p_mean_variance(self, model, x, t):  # Model.py:314-325
+        model.n_steps = self.steps
+        model_output = model(x, t, False)
+        model_log_variance = self._extract_into_tensor(self.posterior_log_variance_clipped, t, x.shape)
+        model_mean = (self._extract_into_tensor(self.posterior_mean_coef1, t, x.shape) * model_output
+                      + self._extract_into_tensor(self.posterior_mean_coef2, t, x.shape) * x)
+        return model_mean, model_log_variance
+
+    def p_sample(self, model, x_start, steps, noise=None):  # Model.py:287-300
+        """All self.steps reverse iterations in one fused launch (the reference loops in Python)."""
+        if steps == 0:
+            x_t = x_start
+        else:
+            t = torch.full((x_start.shape[0],), steps - 1, dtype=torch.long, device=x_start.device)
+            x_t = self.q_sample(x_start, t, noise)
+        dev = x_start.device
+        p = model.params(bool(model.norm))
+        p.time_bias(self.steps, refresh=True)
+        return ops.p_sample_loop(p, x_t.contiguous(), self._dev("posterior_mean_coef1", dev),
+                                 self._dev("posterior_mean_coef2", dev))
+
+    def training_losses2(self, model, targetEmbeds, x_start, batch, ts=None, noise=None):  # Model.py:348-366
+        n = x_start.size(0)
+        dev = x_start.device
+        if ts is None:
+            ts = torch.randint(0, self.steps, (n,), device=dev).long()
+        if noise is None and self.noise_scale != 0:
+            noise = torch.randn_like(x_start)
+        norm = bool(model.norm)
+        xs = x_start.contiguous()
+        if model.training and model.drop.p > 0:
+            raise DiffGraphHipError("training-mode dropout inside training_losses2 is not fused; call model.eval() "
+                                    "(the reference runs with dropout off after its first epoch)")
+        p = model.params(norm)
+        p.time_bias(self.steps, refresh=True)
+        sa = self._dev("sqrt_alphas_cumprod", dev) if self.noise_scale != 0 else None
+        sb = self._dev("sqrt_one_minus_alphas_cumprod", dev) if self.noise_scale != 0 else None
+        row_loss, out, _ = ops.diffusion_loss_fwd(p, targetEmbeds.contiguous(), xs, noise, ts, sa, sb,
+                                                  self._dev("loss_weight", dev, torch.float64))
+        return row_loss[batch], out
+
+    def mean_flat(self, tensor):  # Model.py:368-369
+        return tensor.mean(dim=list(range(1, len(tensor.shape))))
+
+    def SNR(self, t):  # Model.py:371-373
+        ac = self.alphas_cumprod.to(t.device)
+        return ac[t] / (1 - ac[t])

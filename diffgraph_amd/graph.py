@@ -1,0 +1,93 @@
+"""CSRGraph: the graph handle the propagation layers take in place of a dgl.DGLGraph.
+
+The reference builds its graphs with dgl.graph((src, dst), num_nodes=...) from the
+bipartite block adjacency (DiffGraph-Rec/DataHandler.py:120-132) or dgl.from_scipy
+(DiffGraph_NC/DataHandler.py:174).  CSRGraph takes the same directed edge list and owns a
+device-side CSR + degree norms + row schedule created by dg_graph_create.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+class CSRGraph:
+    def __init__(self, src, dst, num_nodes: int, group_max: int = 0, seg_len: int = 0):
+        src = np.ascontiguousarray(np.asarray(src), dtype=np.int32)
+        dst = np.ascontiguousarray(np.asarray(dst), dtype=np.int32)
+        if src.shape != dst.shape or src.ndim != 1:
+            raise ValueError("src and dst must be 1-D arrays of equal length")
+        lib = _lib.load()
+        h = C.c_void_p()
+        rc = lib.dg_graph_create(int(num_nodes), int(src.size), src.ctypes.data, dst.ctypes.data,
+                                 int(group_max), int(seg_len), C.byref(h))
+        _lib.check(rc, "dg_graph_create")
+        self._h = h
+        self._n = int(num_nodes)
+        self._nnz = int(src.size)
+
+    # -- constructors mirroring the reference's DataHandler helpers --------------------
+    @classmethod
+    def from_bipartite(cls, user, item, n_user: int, n_item: int, **kw) -> "CSRGraph":
+        """makeBiAdj (DiffGraph-Rec/DataHandler.py:120-132): [[0, R], [R^T, 0]] over n_user+n_item nodes."""
+        user = np.asarray(user, dtype=np.int32)
+        item = np.asarray(item, dtype=np.int32)
+        src = np.concatenate([user, item + n_user])
+        dst = np.concatenate([item + n_user, user])
+        return cls(src, dst, n_user + n_item, **kw)
+
+    @classmethod
+    def from_scipy(cls, mat, **kw) -> "CSRGraph":
+        """dgl.from_scipy: edge (row -> col) for every stored entry; weights are ignored, as copy_u does."""
+        coo = mat.tocoo()
+        return cls(coo.row, coo.col, coo.shape[0], **kw)
+
+    # -- the few DGLGraph attributes callers use --------------------------------------
+    @property
+    def handle(self) -> C.c_void_p:
+        if self._h is None:
+            raise _lib.DiffGraphHipError("graph handle already destroyed")
+        return self._h
+
+    def num_nodes(self) -> int:
+        return self._n
+
+    def num_edges(self) -> int:
+        return self._nnz
+
+    @property
+    def is_symmetric(self) -> bool:
+        return bool(_lib.load().dg_graph_is_symmetric(self.handle))
+
+    def _export(self, which: int, count: int, dtype) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        rc = _lib.load().dg_graph_export(self.handle, which, out.ctypes.data, out.nbytes)
+        _lib.check(rc, "dg_graph_export")
+        return out
+
+    def csr(self) -> Tuple[np.ndarray, np.ndarray]:
+        return self._export(0, self._n + 1, np.int32), self._export(1, self._nnz, np.int32)
+
+    def norms(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(out-degree norm, in-degree norm) = clamp(deg,1)^-1/2, fp32."""
+        return self._export(2, self._n, np.float32), self._export(3, self._n, np.float32)
+
+    def schedule(self) -> dict:
+        c = self._export(5, 4, np.int32)
+        return {"row_order": self._export(4, self._n, np.int32), "n_hub": int(c[0]), "n_wave": int(c[1]),
+                "n_group": int(c[2]), "n_seg": int(c[3])}
+
+    def close(self) -> None:
+        if self._h is not None:
+            _lib.load().dg_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

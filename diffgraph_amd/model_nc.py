@@ -1,0 +1,102 @@
+"""HGDM for node classification with the reference's interface (DiffGraph_NC/Model.py:18-108).
+
+forward(he_adjs, feature_list, is_training=True) -> (source1, source2, target)
+cal_loss(ancs, label, he_adjs, initial_feature) -> (nll_loss, diff_loss)
+get_allembeds(he_adjs, initial_feature) -> (all_embeddings, scores)
+
+he_adjs is a list of three CSRGraph (author-author meta-path graphs).  Unlike the Rec
+model, the NORMALISED activation of a layer feeds the next one (Model.py:53,60,67).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from ._lib import DG_D, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE
+from .diffusion import Denoise, GaussianDiffusion
+from .layers import UUGCNLayer
+
+DEFAULT_ARGS = SimpleNamespace(latdim=64, gcn_layer=3, uugcn_layer=3, dims="[64]", d_emb_size=8, norm=True, steps=200,
+                               noise_scale=1e-5, noise_min=1e-4, noise_max=1e-3, sampling_steps=0,
+                               batch=8)  # DiffGraph_NC/params.py:5-68
+
+
+class HGDM(nn.Module):
+    def __init__(self, f_dim, args=None, device="cuda"):
+        super().__init__()
+        self.args = args = args or DEFAULT_ARGS
+        if args.latdim != DG_D:
+            raise NotImplementedError(f"kernels are built for latdim={DG_D}")
+        if args.gcn_layer != args.uugcn_layer:
+            raise NotImplementedError("fused forward assumes gcn_layer == uugcn_layer (the reference defaults)")
+        out_dims = eval(args.dims) + [args.latdim]
+        in_dims = out_dims[::-1]
+        self.user_denoise_model = Denoise(in_dims, out_dims, args.d_emb_size, norm=args.norm).to(device)
+        self.diffusion_model = GaussianDiffusion(args.noise_scale, args.noise_min, args.noise_max, args.steps)
+        self.act = nn.LeakyReLU(0.5, inplace=True)
+        mk = lambda: UUGCNLayer(args.latdim, args.latdim, weight=False, bias=False, activation=self.act)
+        self.helayers1 = nn.ModuleList([mk() for _ in range(args.gcn_layer)])
+        self.helayers2 = nn.ModuleList([mk() for _ in range(args.gcn_layer)])
+        self.main_layers = nn.ModuleList([mk() for _ in range(args.uugcn_layer)])
+        self.transform_layer = nn.Linear(f_dim, args.latdim, bias=True).to(device)
+        nn.init.xavier_normal_(self.transform_layer.weight, gain=1.414)
+        self.dense = nn.Linear(args.latdim, 4).to(device)
+
+    def propagate(self, he_adjs, embed: torch.Tensor):
+        """(sum over layers for he_adjs[0], [1], [2]) -- Model.py:52-71."""
+        slope = float(self.act.negative_slope)
+        L = self.args.gcn_layer
+        sums = [torch.empty_like(embed) for _ in he_adjs]
+        prev: List[Optional[torch.Tensor]] = [None] * len(he_adjs)
+        for l in range(L):
+            last = l == L - 1
+            tasks = []
+            for g, graph in enumerate(he_adjs):
+                e_out = None if last else torch.empty_like(embed)
+                flags = (DG_IN_PRESCALED if l > 0 else 0) | (0 if last else DG_OUT_PRESCALE | DG_OUT_NORM)
+                tasks.append(ops.LayerTask(graph, embed if l == 0 else prev[g], e_out, embed if l == 0 else sums[g],
+                                           sums[g], flags, slope))
+                prev[g] = e_out
+            # graphs that share a handle cannot share a launch (one hub slab per handle)
+            seen, batch = set(), []
+            for t in tasks:
+                if id(t.graph) in seen:
+                    ops.gcn_layer_batched(batch)
+                    seen, batch = set(), []
+                seen.add(id(t.graph))
+                batch.append(t)
+            ops.gcn_layer_batched(batch)
+        return sums
+
+    def forward(self, he_adjs, feature_list, is_training=True):
+        embed = self.transform_layer(feature_list).detach().contiguous()
+        target, s1, s2 = self.propagate(he_adjs, embed)
+        return s1, s2, target
+
+    def cal_loss(self, ancs, label, he_adjs, initial_feature, ts=None, noise=None):  # Model.py:75-89
+        s1, s2, target_embedding = self.forward(he_adjs, initial_feature)
+        source_embeddings = s1 + s2
+        diff_loss, diff_embeddings = self.diffusion_model.training_losses2(
+            self.user_denoise_model, target_embedding, source_embeddings, ancs, ts, noise)
+        diff_loss = diff_loss.mean()
+        all_embeddings = target_embedding + diff_embeddings
+        scores = F.log_softmax(self.dense(all_embeddings), dim=1)
+        batch_u = scores[ancs]
+        batch_label = torch.argmax(label[ancs], dim=-1)
+        return F.nll_loss(batch_u, batch_label), diff_loss
+
+    def get_embeds(self, ancs, label, he_adjs, initial_feature):  # Model.py:90-99
+        all_embeddings, _ = self.get_allembeds(he_adjs, initial_feature)
+        return all_embeddings[ancs]
+
+    def get_allembeds(self, he_adjs, initial_feature):  # Model.py:100-108
+        s1, s2, target_embedding = self.forward(he_adjs, initial_feature)
+        source_embeddings = s1 + s2
+        diff_embeddings = self.diffusion_model.p_sample(self.user_denoise_model, source_embeddings, self.args.sampling_steps)
+        all_embeddings = target_embedding + diff_embeddings
+        return all_embeddings, self.dense(all_embeddings)

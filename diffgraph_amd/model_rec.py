@@ -1,0 +1,122 @@
+"""HGDM for recommendation with the reference's interface (DiffGraph-Rec/Model.py:16-118).
+
+forward() -> (target_user, target_item, heter_user, heter_item)
+cal_loss(ancs, poss, negs) -> (loss, bprLoss, regLoss, diff_loss)
+predict() -> (usrEmbeds, itmEmbeds)
+
+`data_handler` needs userNum, itemNum, target_adj (CSRGraph) and behavior_mats (sequence or
+dict of CSRGraph), as the reference's DataHandler provides with DGL graphs.
+
+The propagation runs as one fused launch per layer over all (1 + B) graphs: layer l of graph
+g reads the previous layer's activation already scaled by the source-node norm, writes the
+next one, and adds the L2-normalised activation into that graph's running sum.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
+from .diffusion import Denoise, GaussianDiffusion
+from .layers import DGLLayer
+
+DEFAULT_ARGS = SimpleNamespace(latdim=64, gcn_layer=2, dims="[64]", d_emb_size=8, norm=True, steps=200,
+                               noise_scale=1e-4, noise_min=1e-4, noise_max=1e-3, sampling_steps=0, batch=2048,
+                               reg=3e-2)  # DiffGraph-Rec/params.py:5-39
+
+
+def pairPredict(ancEmbeds, posEmbeds, negEmbeds):  # DiffGraph-Rec/Utils/Utils.py:4-8
+    return (ancEmbeds * posEmbeds).sum(-1) - (ancEmbeds * negEmbeds).sum(-1)
+
+
+class HGDM(nn.Module):
+    def __init__(self, data_handler, args=None, device="cuda"):
+        super().__init__()
+        self.args = args = args or DEFAULT_ARGS
+        if args.latdim != DG_D:
+            raise NotImplementedError(f"kernels are built for latdim={DG_D}")
+        self.n_user, self.n_item = data_handler.userNum, data_handler.itemNum
+        bm = data_handler.behavior_mats
+        self.behavior_mats = [bm[k] for k in sorted(bm)] if isinstance(bm, dict) else list(bm)
+        self.target_adj = data_handler.target_adj
+        self.n_hid, self.n_layers = args.latdim, args.gcn_layer
+        # one [n_user+n_item, 64] table; user_emb / item_emb are views, so the concatenation
+        # at Model.py:55-56 costs nothing
+        table = torch.empty(self.n_user + self.n_item, self.n_hid, device=device)
+        nn.init.xavier_uniform_(table[: self.n_user])
+        nn.init.xavier_uniform_(table[self.n_user:])
+        self.embedding_table = nn.Parameter(table)
+        self.act = nn.LeakyReLU(0.5, inplace=True)
+        self.layers = nn.ModuleList(
+            [DGLLayer(self.n_hid, self.n_hid, weight=False, bias=False, activation=self.act) for _ in range(self.n_layers)])
+        self.diffusion_process = GaussianDiffusion(args.noise_scale, args.noise_min, args.noise_max, args.steps)
+        out_dims = eval(args.dims) + [args.latdim]
+        in_dims = out_dims[::-1]
+        self.usr_denoiser = Denoise(in_dims, out_dims, args.d_emb_size, norm=args.norm).to(device)
+        self.item_denoiser = Denoise(in_dims, out_dims, args.d_emb_size, norm=args.norm).to(device)
+
+    @property
+    def embedding_dict(self):
+        return {"user_emb": self.embedding_table[: self.n_user], "item_emb": self.embedding_table[self.n_user:]}
+
+    def set_embeddings(self, user_emb: torch.Tensor, item_emb: torch.Tensor) -> None:
+        with torch.no_grad():
+            self.embedding_table[: self.n_user].copy_(user_emb)
+            self.embedding_table[self.n_user:].copy_(item_emb)
+
+    def propagate(self, e0: torch.Tensor):
+        """Returns (ui_embeddings [N,64], all_heter_embeddings [N,64])  (Model.py:61-87)."""
+        graphs = [self.target_adj] + self.behavior_mats
+        slope = float(self.act.negative_slope)
+        L = self.n_layers
+        sums = [torch.empty_like(e0) for _ in graphs]
+        prev: List[Optional[torch.Tensor]] = [None] * len(graphs)
+        for l in range(L):
+            last = l == L - 1
+            tasks = []
+            for g, graph in enumerate(graphs):
+                e_out = None if last else torch.empty_like(e0)
+                flags = (DG_IN_PRESCALED if l > 0 else 0) | (0 if last else DG_OUT_PRESCALE)
+                tasks.append(ops.LayerTask(graph, e0 if l == 0 else prev[g], e_out, e0 if l == 0 else sums[g], sums[g],
+                                           flags, slope))
+                prev[g] = e_out
+            hook = getattr(self, "layer_hook", None)
+            if hook is not None:
+                hook("begin", l)
+            ops.gcn_layer_batched(tasks)
+            if hook is not None:
+                hook("end", l)
+        return sums[0], ops.sum_tables(sums[1:])
+
+    def forward(self):
+        e0 = self.embedding_table.detach()
+        ui, het = self.propagate(e0)
+        nu = self.n_user
+        return ui[:nu], ui[nu:], het[:nu], het[nu:]
+
+    def cal_loss(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None):  # Model.py:94-111
+        args = self.args
+        usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = self.forward()
+        dp = self.diffusion_process
+        u_diff_loss, diff_usrEmbeds = dp.training_losses2(self.usr_denoiser, usrEmbeds, h_usrEmbeds, ancs, ts_u, noise_u)
+        i_diff_loss, diff_itemEmbeds = dp.training_losses2(self.item_denoiser, itmEmbeds, h_itemEmbeds, poss, ts_i, noise_i)
+        diff_loss = u_diff_loss.mean() + i_diff_loss.mean()
+        usrEmbeds = usrEmbeds + diff_usrEmbeds
+        itmEmbeds = itmEmbeds + diff_itemEmbeds
+        ancEmbeds, posEmbeds, negEmbeds = usrEmbeds[ancs], itmEmbeds[poss], itmEmbeds[negs]
+        scoreDiff = pairPredict(ancEmbeds, posEmbeds, negEmbeds)
+        bprLoss = -(scoreDiff).sigmoid().log().sum() / args.batch
+        regLoss = ((torch.norm(ancEmbeds) ** 2 + torch.norm(posEmbeds) ** 2 + torch.norm(negEmbeds) ** 2) * args.reg) / args.batch
+        loss = bprLoss + regLoss + diff_loss
+        return loss, bprLoss, regLoss, diff_loss
+
+    def predict(self):  # Model.py:112-118
+        usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = self.forward()
+        dp = self.diffusion_process
+        denoised_u = dp.p_sample(self.usr_denoiser, h_usrEmbeds, self.args.sampling_steps)
+        denoised_i = dp.p_sample(self.item_denoiser, h_itemEmbeds, self.args.sampling_steps)
+        return usrEmbeds + denoised_u, itmEmbeds + denoised_i

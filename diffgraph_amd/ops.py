@@ -1,0 +1,208 @@
+"""Functional wrappers: torch tensors in, HIP kernels through the C ABI, torch tensors out.
+
+torch is plumbing here (device memory, streams); every op below is one call into
+libdiffgraph_hip.so.  All wrappers validate shapes/dtypes/devices on the host before a
+kernel is launched.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import DG_D, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE, DiffGraphHipError
+from .graph import CSRGraph
+
+
+def _table(x: torch.Tensor, name: str, rows: Optional[int] = None) -> torch.Tensor:
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise DiffGraphHipError(f"{name}: expected a tensor on the GPU")
+    if x.dtype != torch.float32:
+        raise DiffGraphHipError(f"{name}: expected float32, got {x.dtype}")
+    if x.dim() != 2 or x.shape[1] != DG_D:
+        raise DiffGraphHipError(f"{name}: expected shape [rows,{DG_D}], got {tuple(x.shape)}")
+    if rows is not None and x.shape[0] != rows:
+        raise DiffGraphHipError(f"{name}: expected {rows} rows, got {x.shape[0]}")
+    if not x.is_contiguous():
+        raise DiffGraphHipError(f"{name}: tensor must be contiguous")
+    return x
+
+
+def _vec(x: torch.Tensor, name: str, dtype, count: Optional[int] = None) -> torch.Tensor:
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != dtype or x.dim() != 1 or not x.is_contiguous():
+        raise DiffGraphHipError(f"{name}: expected a contiguous 1-D {dtype} tensor on the GPU")
+    if count is not None and x.numel() != count:
+        raise DiffGraphHipError(f"{name}: expected {count} elements, got {x.numel()}")
+    return x
+
+
+def _ptr(x: Optional[torch.Tensor]) -> Optional[int]:
+    return None if x is None else x.data_ptr()
+
+
+# --------------------------------------------------------------------------------------
+# propagation
+# --------------------------------------------------------------------------------------
+def spmm_norm_act(graph: CSRGraph, x: torch.Tensor, slope: float = 0.5, transpose: bool = False) -> torch.Tensor:
+    """y = LeakyReLU_slope(dinv_dst * sum_{j->i} dinv_src[j] x[j])  (DGLLayer.forward, Model.py:142-174)."""
+    _table(x, "x", graph.num_nodes())
+    y = torch.empty_like(x)
+    rc = _lib.load().dg_spmm_norm_act_fwd(graph.handle, x.data_ptr(), y.data_ptr(), DG_D, float(slope),
+                                          int(transpose), _lib.stream_ptr(x.device))
+    _lib.check(rc, "dg_spmm_norm_act_fwd")
+    return y
+
+
+@dataclass
+class LayerTask:
+    graph: CSRGraph
+    x: torch.Tensor
+    e_out: Optional[torch.Tensor] = None
+    acc_in: Optional[torch.Tensor] = None
+    acc_out: Optional[torch.Tensor] = None
+    flags: int = 0
+    slope: float = 0.5
+
+
+def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
+    """One fused propagation layer (SpMM + LeakyReLU + normalise + layer sum) over several graphs."""
+    if not tasks:
+        return
+    n_tasks = len(tasks)
+    if n_tasks > _lib.DG_MAX_TASKS:
+        raise DiffGraphHipError(f"at most {_lib.DG_MAX_TASKS} graphs per batched layer launch")
+    arr = (_lib.LayerTask * n_tasks)()
+    dev = tasks[0].x.device
+    for k, t in enumerate(tasks):
+        n = t.graph.num_nodes()
+        _table(t.x, "x", n)
+        for nm in ("e_out", "acc_in", "acc_out"):
+            v = getattr(t, nm)
+            if v is not None:
+                _table(v, nm, n)
+        arr[k] = _lib.LayerTask(t.graph.handle, t.x.data_ptr(), _ptr(t.e_out), _ptr(t.acc_in), _ptr(t.acc_out),
+                                int(t.flags), float(t.slope))
+    rc = _lib.load().dg_gcn_layer_fwd(arr, n_tasks, DG_D, _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_gcn_layer_fwd")
+
+
+def sum_tables(tables: Sequence[torch.Tensor]) -> torch.Tensor:
+    """((t0 + t1) + t2) + ... like Python's sum(list) (Model.py:87)."""
+    if len(tables) == 1:
+        return tables[0]
+    for t in tables:
+        _table(t, "table", tables[0].shape[0])
+    out = torch.empty_like(tables[0])
+    ptrs = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
+    rc = _lib.load().dg_sum_tables(ptrs, len(tables), out.data_ptr(), out.numel(), _lib.stream_ptr(out.device))
+    _lib.check(rc, "dg_sum_tables")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# diffusion
+# --------------------------------------------------------------------------------------
+class DenoiserParams:
+    """Device pointers + host frequencies of one Denoise module, and its per-timestep bias table."""
+
+    def __init__(self, w_emb, b_emb, w_in, b_in, w_out, b_out, norm: bool = True):
+        if tuple(w_emb.shape) != (8, 8) or tuple(w_in.shape) != (DG_D, DG_D + 8) or tuple(w_out.shape) != (DG_D, DG_D):
+            raise DiffGraphHipError("denoiser weights must be emb 8x8, in 64x72, out 64x64 (dims='[64]', d_emb_size=8)")
+        self.tensors = [t.detach().contiguous() for t in (w_emb, b_emb, w_in, b_in, w_out, b_out)]
+        for t in self.tensors:
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise DiffGraphHipError("denoiser weights must be float32 GPU tensors")
+        half = 4
+        # Model.py:215 -- evaluated with the same torch CPU ops as the reference
+        freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+        self._freqs = (C.c_float * 4)(*[float(f) for f in freqs])
+        self.c = _lib.Denoiser(*[t.data_ptr() for t in self.tensors], self._freqs, int(bool(norm)))
+        self.device = self.tensors[0].device
+        self._tb = None
+        self._tb_steps = 0
+
+    def time_bias(self, n_steps: int, refresh: bool = False) -> torch.Tensor:
+        if self._tb is None or self._tb_steps != n_steps or refresh:
+            tb = torch.empty((n_steps, DG_D), dtype=torch.float32, device=self.device)
+            rc = _lib.load().dg_time_bias_table(C.byref(self.c), n_steps, tb.data_ptr(), _lib.stream_ptr(self.device))
+            _lib.check(rc, "dg_time_bias_table")
+            self._tb, self._tb_steps = tb, n_steps
+        return self._tb
+
+
+def _check_t(t: torch.Tensor, n: int, n_steps: int, validate: bool) -> torch.Tensor:
+    _vec(t, "timesteps", torch.int64, n)
+    if validate and n > 0:
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= n_steps:
+            raise DiffGraphHipError(f"timesteps must lie in [0,{n_steps}); got [{lo},{hi}]")
+    return t
+
+
+def q_sample(x0: torch.Tensor, noise: torch.Tensor, t: torch.Tensor, sqrt_ac: torch.Tensor, sqrt_1mac: torch.Tensor,
+             validate: bool = True) -> torch.Tensor:
+    _table(x0, "x_start")
+    _table(noise, "noise", x0.shape[0])
+    n_steps = sqrt_ac.numel()
+    _vec(sqrt_ac, "sqrt_alphas_cumprod", torch.float32)
+    _vec(sqrt_1mac, "sqrt_one_minus_alphas_cumprod", torch.float32, n_steps)
+    _check_t(t, x0.shape[0], n_steps, validate)
+    out = torch.empty_like(x0)
+    rc = _lib.load().dg_q_sample(x0.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(),
+                                 n_steps, x0.shape[0], DG_D, out.data_ptr(), _lib.stream_ptr(x0.device))
+    _lib.check(rc, "dg_q_sample")
+    return out
+
+
+def denoise_fwd(dn: DenoiserParams, x: torch.Tensor, t: torch.Tensor, n_steps: int, validate: bool = True) -> torch.Tensor:
+    _table(x, "x")
+    _check_t(t, x.shape[0], n_steps, validate)
+    tb = dn.time_bias(n_steps)
+    out = torch.empty_like(x)
+    rc = _lib.load().dg_denoise_fwd(C.byref(dn.c), tb.data_ptr(), n_steps, x.data_ptr(), t.data_ptr(), x.shape[0], DG_D,
+                                    out.data_ptr(), _lib.stream_ptr(x.device))
+    _lib.check(rc, "dg_denoise_fwd")
+    return out
+
+
+def p_sample_loop(dn: DenoiserParams, x_T: torch.Tensor, coef1: torch.Tensor, coef2: torch.Tensor) -> torch.Tensor:
+    _table(x_T, "x_T")
+    n_steps = coef1.numel()
+    _vec(coef1, "posterior_mean_coef1", torch.float32)
+    _vec(coef2, "posterior_mean_coef2", torch.float32, n_steps)
+    tb = dn.time_bias(n_steps)
+    out = torch.empty_like(x_T)
+    rc = _lib.load().dg_p_sample_loop(C.byref(dn.c), tb.data_ptr(), coef1.data_ptr(), coef2.data_ptr(), n_steps,
+                                      x_T.data_ptr(), x_T.shape[0], DG_D, out.data_ptr(), _lib.stream_ptr(x_T.device))
+    _lib.check(rc, "dg_p_sample_loop")
+    return out
+
+
+def diffusion_loss_fwd(dn: DenoiserParams, target: torch.Tensor, x_start: torch.Tensor, noise: Optional[torch.Tensor],
+                       ts: torch.Tensor, sqrt_ac: Optional[torch.Tensor], sqrt_1mac: Optional[torch.Tensor],
+                       loss_w: torch.Tensor, want_x_t: bool = False, validate: bool = True):
+    """Returns (row_loss fp64 [n], out [n,64], x_t or None)."""
+    n = x_start.shape[0]
+    _table(x_start, "x_start")
+    _table(target, "targetEmbeds", n)
+    n_steps = loss_w.numel()
+    _vec(loss_w, "loss weights", torch.float64)
+    _check_t(ts, n, n_steps, validate)
+    if sqrt_ac is not None:
+        _table(noise, "noise", n)
+        _vec(sqrt_ac, "sqrt_alphas_cumprod", torch.float32, n_steps)
+        _vec(sqrt_1mac, "sqrt_one_minus_alphas_cumprod", torch.float32, n_steps)
+    tb = dn.time_bias(n_steps)
+    out = torch.empty_like(x_start)
+    row_loss = torch.empty(n, dtype=torch.float64, device=x_start.device)
+    x_t = torch.empty_like(x_start) if (want_x_t and sqrt_ac is not None) else None
+    rc = _lib.load().dg_diffusion_loss_fwd(C.byref(dn.c), tb.data_ptr(), n_steps, target.data_ptr(), x_start.data_ptr(),
+                                           _ptr(noise) if sqrt_ac is not None else None, ts.data_ptr(), _ptr(sqrt_ac),
+                                           _ptr(sqrt_1mac), loss_w.data_ptr(), n, DG_D, out.data_ptr(),
+                                           row_loss.data_ptr(), _ptr(x_t), _lib.stream_ptr(x_start.device))
+    _lib.check(rc, "dg_diffusion_loss_fwd")
+    return row_loss, out, x_t

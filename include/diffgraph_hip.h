@@ -1,0 +1,163 @@
+/*
+ * diffgraph_hip.h -- C ABI of libdiffgraph_hip.so (MI355X / gfx950).
+ *
+ * Hand-written HIP kernels for DiffGraph's per-epoch compute hot path: normalised-adjacency
+ * propagation with fused LeakyReLU / row-L2-normalise / layer-sum epilogue, and the latent
+ * diffusion q_sample / denoiser / reverse p_sample loop.
+ *
+ * The reference (preetam1407/DiffGraph) is pure Python over DGL + PyTorch and defines no
+ * FFI of its own; each entry point below names the Python method (file:line, relative to
+ * the reference checkout) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - Every `const float*` / `float*` / `const int64_t*` data argument is a DEVICE pointer
+ *     owned by the caller (in practice a torch tensor's data_ptr()); the library never
+ *     frees or retains it.  Host-pointer arguments say so in their name (`*_host`).
+ *   - Embedding tables are row-major fp32 [rows][64]; D must be 64 (other values -> -2).
+ *   - `stream` is a hipStream_t passed as void*; all launches are asynchronous on it.
+ *   - Return value: 0 ok; <0 argument error (dg_last_error() has the text);
+ *     >0 a hipError_t from the runtime.
+ *   - Re-entrant from any host thread; a dg_graph handle is immutable after creation and
+ *     may be shared between threads/streams, except for its hub scratch slab, which
+ *     calls on the same handle share (serialise them on one stream).
+ */
+#ifndef DIFFGRAPH_HIP_H
+#define DIFFGRAPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_D 64                 /* embedding width the kernels are built for */
+#define DG_MAX_TASKS 8          /* graphs per batched layer launch */
+
+int dg_version(void);
+const char *dg_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Graph handle: replaces the dgl.DGLGraph the reference builds in
+ * DiffGraph-Rec/DataHandler.py:120-132 (makeBiAdj: dgl.graph((src,dst), num_nodes)) and
+ * DiffGraph_NC/DataHandler.py:174 (dgl.from_scipy).  Edges are directed src -> dst;
+ * duplicates count (multigraph), as in DGL.  The handle owns device copies of the CSR
+ * (by destination), of out/in-degree norms  max(deg,1)^-1/2  (fp32, computed once; the
+ * reference recomputes them on every layer call, Model.py:151-152,165-166) and of a
+ * degree-binned row schedule.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dg_graph dg_graph;
+
+/* group_max / seg_len: schedule knobs, 0 = library default (rows with in-degree <=
+ * group_max are summed by one 16-lane group, <= seg_len by one wavefront, longer rows are
+ * split into seg_len-neighbour segments whose partial sums go through a scratch slab). */
+int dg_graph_create(int32_t n_nodes, int64_t n_edges, const int32_t *src_host,
+                    const int32_t *dst_host, int32_t group_max, int32_t seg_len,
+                    dg_graph **out);
+void dg_graph_destroy(dg_graph *g);
+int32_t dg_graph_num_nodes(const dg_graph *g);
+int64_t dg_graph_num_edges(const dg_graph *g);
+/* 1 if the edge set equals its transpose (then forward and backward share one CSR). */
+int dg_graph_is_symmetric(const dg_graph *g);
+/* Copy schedule/CSR facts back to the host for tests: which = 0 rowptr[n+1], 1 colidx[nnz],
+ * 2 dinv_src[n] (float bits), 3 dinv_dst[n], 4 row_order[n], 5 counts {n_hub,n_wave,n_group,n_seg}. */
+int dg_graph_export(const dg_graph *g, int which, void *dst_host, size_t dst_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * a1: one propagation layer.  Replaces DGLLayer.forward(graph,u_f,v_f)
+ * (DiffGraph-Rec/Model.py:142-174) and UUGCNLayer.forward(graph,u_f)
+ * (DiffGraph_NC/Model.py:184-214):
+ *     y = LeakyReLU_slope( dinv_dst (.) sum_{j->i} dinv_src[j] * x[j] )
+ * x, y: [n_nodes][64].  slope = 1.0f gives the activation-free form.
+ * transpose != 0 propagates along reversed edges (used by the backward pass).
+ * ---------------------------------------------------------------------------------- */
+int dg_spmm_norm_act_fwd(dg_graph *g, const float *x, float *y, int32_t d, float slope,
+                         int transpose, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * a1+a4 fused, batched over the graphs of one propagation layer.  Replaces one iteration
+ * of the per-graph layer loops in HGDM.forward (DiffGraph-Rec/Model.py:61-70,73-87;
+ * DiffGraph_NC/Model.py:52-71): layer call + F.normalize(p=2,dim=1) + running layer sum.
+ * For task k, with y = LeakyReLU(...) as above and yn = y / max(||y||_2, 1e-12):
+ *     if e_out:   e_out[i]   = (DG_OUT_NORM ? yn : y) * (DG_OUT_PRESCALE ? dinv_src[i] : 1)
+ *     if acc_out: acc_out[i] = acc_in[i] + yn
+ * DG_IN_PRESCALED says x already carries the dinv_src[j] factor (written by a previous
+ * call with DG_OUT_PRESCALE), so the gather is a plain sum.
+ * All tasks run in ONE launch (plus one for hub-row partial sums when any graph has them).
+ * ---------------------------------------------------------------------------------- */
+enum { DG_IN_PRESCALED = 1, DG_OUT_NORM = 2, DG_OUT_PRESCALE = 4 };
+
+typedef struct dg_layer_task {
+  dg_graph *graph;
+  const float *x;        /* gather source [n][64] */
+  float *e_out;          /* next layer's input, or NULL */
+  const float *acc_in;   /* running layer sum in, or NULL iff acc_out is NULL */
+  float *acc_out;        /* running layer sum out (may alias acc_in), or NULL */
+  int32_t flags;
+  float slope;
+} dg_layer_task;
+
+int dg_gcn_layer_fwd(const dg_layer_task *tasks, int32_t n_tasks, int32_t d, void *stream);
+
+/* out[i] = ((in[0][i] + in[1][i]) + in[2][i]) ... left to right; replaces Python
+ * sum(list) over per-behaviour sums (DiffGraph-Rec/Model.py:87).  n_in <= 8. */
+int dg_sum_tables(const float *const *in_host, int32_t n_in, float *out, int64_t n_elems,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * a6: q_sample.  Replaces GaussianDiffusion.q_sample + _extract_into_tensor
+ * (DiffGraph-Rec/Model.py:302-312):  x_t[i] = sqrt_ac[t_i]*x0[i] + sqrt_1mac[t_i]*noise[i].
+ * sqrt_ac / sqrt_1mac: DEVICE fp32 tables of length n_steps (the fp64 host tables cast to
+ * fp32, which equals the reference's index-then-cast).  t: int64[n], each in [0,n_steps).
+ * ---------------------------------------------------------------------------------- */
+int dg_q_sample(const float *x0, const float *noise, const int64_t *t, const float *sqrt_ac,
+                const float *sqrt_1mac, int32_t n_steps, int64_t n, int32_t d, float *x_t,
+                void *stream);
+
+/* Denoiser parameters, torch nn.Linear layout [out][in] (DiffGraph-Rec/Model.py:184-191
+ * with dims='[64]', d_emb_size=8): emb_layer 8x8, in_layers[0] 64x72, out_layers[0] 64x64.
+ * freqs: the 4 fp32 frequencies exp(-ln(1e4)*k/4) (Model.py:215), HOST pointer. */
+typedef struct dg_denoiser {
+  const float *w_emb, *b_emb;   /* [8][8], [8]   device */
+  const float *w_in, *b_in;     /* [64][72], [64] device */
+  const float *w_out, *b_out;   /* [64][64], [64] device */
+  const float *freqs_host;      /* [4] host */
+  int32_t norm;                 /* Denoise.norm (args.norm, default True) */
+} dg_denoiser;
+
+/* Workspace the denoiser kernels need: a [n_steps][64] fp32 per-timestep bias table
+ * b_in + W_in[:,64:72] . emb_layer([cos(t f), sin(t f)])  (Model.py:215-220,225-227).
+ * dg_time_bias_table fills it (device pointer, n_steps*64 floats). */
+int dg_time_bias_table(const dg_denoiser *dn, int32_t n_steps, float *table, void *stream);
+
+/* a7: Denoise.forward(x, timesteps, mess_dropout=False) (DiffGraph-Rec/Model.py:214-234),
+ * eval-mode arithmetic.  x,out: [n][64]; t: int64[n] in [0,n_steps); table from above. */
+int dg_denoise_fwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps, const float *x,
+                   const int64_t *t, int64_t n, int32_t d, float *out, void *stream);
+
+/* a8: GaussianDiffusion.p_sample(model, x_start, steps=0) reverse loop
+ * (DiffGraph-Rec/Model.py:287-300 with p_mean_variance :314-325): for i = n_steps-1..0:
+ *     x <- coef1[i]*Denoise(x, i) + coef2[i]*x
+ * run entirely in registers, one launch.  coef1/coef2: DEVICE fp32 tables (posterior mean
+ * coefficients cast to fp32).  x_T is the caller's job (steps==0 -> x_start itself;
+ * otherwise dg_q_sample first).  x_T and x_0 may alias. */
+int dg_p_sample_loop(const dg_denoiser *dn, const float *time_bias, const float *coef1,
+                     const float *coef2, int32_t n_steps, const float *x_T, int64_t n, int32_t d,
+                     float *x_0, void *stream);
+
+/* a9: GaussianDiffusion.training_losses2 forward (DiffGraph-Rec/Model.py:348-366) with the
+ * random draws supplied by the caller: x_t = q_sample(x_start, ts, noise) (skipped when
+ * sqrt_ac == NULL, the noise_scale == 0 case), out = Denoise(x_t, ts),
+ * row_loss[i] = loss_w[ts_i] * mean_j (target[i][j]-out[i][j])^2   (fp64, weight table
+ * loss_w = SNR(t-1)-SNR(t), 1 at t=0, DEVICE fp64[n_steps]).  The caller gathers
+ * row_loss[batch].  x_t_out (nullable) receives x_t for the backward pass. */
+int dg_diffusion_loss_fwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps,
+                          const float *target, const float *x_start, const float *noise,
+                          const int64_t *ts, const float *sqrt_ac, const float *sqrt_1mac,
+                          const double *loss_w, int64_t n, int32_t d, float *out, double *row_loss,
+                          float *x_t_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFGRAPH_HIP_H */

@@ -1,0 +1,174 @@
+"""Pins the CPU oracle (oracle/ref_cpu.py) to golden vectors captured from the reference's
+own Model.py (tools/make_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from diffgraph_amd import data as dgdata
+from oracle import ref_cpu as O
+from tests.helpers import (NC_TABLE, REC_TABLE, assert_rows_close, edges_t, load, tiny_fixture, weights_from)
+
+T = torch.from_numpy
+
+
+def test_tables_bit_exact():
+    fx = load("rec_tiny.npz")
+    tab = O.DiffusionTables(**REC_TABLE)
+    for nm in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+               "sqrt_one_minus_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+               "posterior_mean_coef1", "posterior_mean_coef2"):
+        got = getattr(tab, nm).numpy()
+        assert got.dtype == np.float64
+        np.testing.assert_array_equal(got, fx["tab_" + nm], err_msg=nm)
+    nc = load("nc_dblp.npz")
+    tab = O.DiffusionTables(**NC_TABLE)
+    for nm in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+               "posterior_mean_coef1", "posterior_mean_coef2"):
+        np.testing.assert_array_equal(getattr(tab, nm).numpy(), nc["tab_" + nm], err_msg=nm)
+    # facts the kernels rely on: the last reverse step is out*1 + x*0 in fp32
+    tab = O.DiffusionTables(**REC_TABLE)
+    assert np.float32(tab.posterior_mean_coef1[0].item()) == np.float32(1.0)
+    assert tab.posterior_mean_coef2[0].item() == 0.0
+
+
+def test_layer_and_forward_tiny():
+    fx, nu, ni, target, behs = tiny_fixture()
+    ue, ie = T(fx["user_emb"]), T(fx["item_emb"])
+    y = O.gcn_layer(target[0], target[1], nu + ni, torch.cat([ue, ie]))
+    np.testing.assert_array_equal(y.numpy(), fx["layer_y"])  # same ops, same order: bit-exact
+    outs = O.rec_forward(target, behs, ue, ie, 2)
+    for o, nm in zip(outs, ("fwd_tu", "fwd_ti", "fwd_hu", "fwd_hi")):
+        np.testing.assert_array_equal(o.numpy(), fx[nm], err_msg=nm)
+    # edge cases present in the tiny graph: isolated user/item rows give exactly e0 (+0 per layer)
+    np.testing.assert_array_equal(outs[0][nu - 1].numpy(), fx["user_emb"][nu - 1])
+    np.testing.assert_array_equal(outs[1][ni - 1].numpy(), fx["item_emb"][ni - 1])
+
+
+def test_forward_retail_rocket_shape():
+    fx = load("rec_retail_rocket.npz")
+    wl = dgdata.rec_workload("retail_rocket")
+    ue = T(dgdata.xavier_uniform(wl.n_user, 64, seed=0))
+    ie = T(dgdata.xavier_uniform(wl.n_item, 64, seed=1))
+    target = edges_t(*wl.target, wl.n_user)
+    behs = [edges_t(*b, wl.n_user) for b in wl.behaviours]
+    outs = O.rec_forward(target, behs, ue, ie, 2)
+    for o, nm, rows in zip(outs, ("tu", "ti", "hu", "hi"), ("rows_u", "rows_i", "rows_u", "rows_i")):
+        assert_rows_close(o[fx[rows]], fx[f"fwd_{nm}_rows"], what=nm)
+        colsum = o.double().sum(0).numpy()
+        np.testing.assert_allclose(colsum, fx[f"fwd_{nm}_colsum"], rtol=0, atol=1e-5 * fx[f"fwd_{nm}_abssum"].max())
+
+
+def test_q_sample_and_denoise():
+    fx, nu, ni, target, behs = tiny_fixture()
+    tab = O.DiffusionTables(**REC_TABLE)
+    hu = T(fx["fwd_hu"])
+    q = O.q_sample(tab, hu, T(fx["q_t"]), T(fx["q_noise"]))
+    np.testing.assert_array_equal(q.numpy(), fx["q_out"])
+    w = weights_from(fx, "usr_")
+    for tv in (0, 1, 50, 199):
+        out = O.denoise_forward(w, hu, torch.full((nu,), tv, dtype=torch.long))
+        assert_rows_close(out, fx[f"dn_out_t{tv}"], what=f"denoise t={tv}")
+    out = O.denoise_forward(w, hu, T(fx["q_t"]))
+    assert_rows_close(out, fx["dn_out_mixed"], what="denoise mixed t")
+
+
+def test_p_sample():
+    fx, nu, ni, target, behs = tiny_fixture()
+    tab = O.DiffusionTables(**REC_TABLE)
+    hu, hi = T(fx["fwd_hu"]), T(fx["fwd_hi"])
+    x0, kept = O.p_sample(tab, weights_from(fx, "usr_"), hu, 0, keep=(199, 100, 1))
+    assert_rows_close(x0, fx["ps_usr_x0"], what="p_sample x0")
+    for k in (199, 100, 1):
+        assert_rows_close(kept[k], fx[f"ps_usr_after{k}"], what=f"p_sample after step {k}")
+    assert_rows_close(O.p_sample(tab, weights_from(fx, "item_"), hi, 0), fx["ps_item_x0"], what="p_sample item")
+    x0 = O.p_sample(tab, weights_from(fx, "usr_"), hu, 5, noise=T(fx["ps5_noise"]))
+    assert_rows_close(x0, fx["ps5_usr_x0"], what="p_sample steps=5")
+    # predict() glue: emb + denoised
+    assert_rows_close(T(fx["fwd_tu"]) + T(fx["ps_usr_x0"]), fx["predict_u"], what="predict")
+
+
+def test_training_losses2():
+    fx, nu, ni, target, behs = tiny_fixture()
+    tab = O.DiffusionTables(**REC_TABLE)
+    loss, out = O.training_losses2(tab, weights_from(fx, "usr_"), T(fx["fwd_tu"]), T(fx["fwd_hu"]), T(fx["tl_batch"]),
+                                   T(fx["tl_ts"]), T(fx["tl_noise"]))
+    assert loss.dtype == torch.float64
+    assert_rows_close(out, fx["tl_out"], what="tl out")
+    np.testing.assert_allclose(loss.numpy(), fx["tl_loss"], rtol=1e-5)
+    # measured loss weights quoted for the reference defaults
+    w = tab.loss_weight(torch.tensor([0, 1, 199]))
+    assert w[0].item() == 1.0
+    assert abs(w[1].item() - 0.04522140) < 1e-7 and abs(w[2].item() - 0.04514052) < 1e-7
+
+
+def test_cal_loss_and_gradients():
+    """a11: the oracle's forward under torch autograd reproduces the reference's loss values and
+    its gradients wrt the embeddings and denoiser weights."""
+    fx, nu, ni, target, behs = tiny_fixture()
+    tab = O.DiffusionTables(**REC_TABLE)
+    ue = T(fx["user_emb"]).clone().requires_grad_(True)
+    ie = T(fx["item_emb"]).clone().requires_grad_(True)
+    wu, wi = weights_from(fx, "usr_"), weights_from(fx, "item_")
+    for w in (wu, wi):
+        for nm in ("w_emb", "b_emb", "w_in", "b_in", "w_out", "b_out"):
+            setattr(w, nm, getattr(w, nm).clone().requires_grad_(True))
+    ancs, poss, negs = T(fx["cl_ancs"]), T(fx["cl_poss"]), T(fx["cl_negs"])
+    batch, reg = fx["cl_batch_div"]
+    tu, ti, hu, hi = O.rec_forward(target, behs, ue, ie, 2)
+    lu, du = O.training_losses2(tab, wu, tu, hu, ancs, T(fx["cl_ts_u"]), T(fx["cl_noise_u"]))
+    li, di = O.training_losses2(tab, wi, ti, hi, poss, T(fx["cl_ts_i"]), T(fx["cl_noise_i"]))
+    diff = lu.mean() + li.mean()
+    usr, itm = tu + du, ti + di
+    a, p, n = usr[ancs], itm[poss], itm[negs]
+    score = (a * p).sum(-1) - (a * n).sum(-1)
+    bpr = -score.sigmoid().log().sum() / batch
+    regl = ((torch.norm(a) ** 2 + torch.norm(p) ** 2 + torch.norm(n) ** 2) * reg) / batch
+    loss = bpr + regl + diff
+    np.testing.assert_allclose([loss.item(), bpr.item(), regl.item(), diff.item()], fx["cl_losses"], rtol=1e-6)
+    loss.backward()
+    assert_rows_close(ue.grad, fx["cl_grad_user"], rtol=1e-4, what="grad user_emb")
+    assert_rows_close(ie.grad, fx["cl_grad_item"], rtol=1e-4, what="grad item_emb")
+    for pre, w in (("usr_", wu), ("item_", wi)):
+        for nm in ("w_emb", "b_emb", "w_in", "b_in", "w_out", "b_out"):
+            assert_rows_close(getattr(w, nm).grad, fx["cl_grad_" + pre + nm], rtol=1e-4, what="grad " + pre + nm)
+
+
+def _dblp_graphs():
+    import scipy.sparse as sp
+    g = load("dblp_graph.npz")
+    NA, NP, NC, NT = (int(v) for v in g["counts"])
+    mk = lambda e, shape: sp.coo_matrix((np.ones(len(e), dtype=np.float32), (e[:, 0], e[:, 1])), shape=shape).tocsr()
+    A_P, P_C, P_T = mk(g["ap"], (NA, NP)), mk(g["pc"], (NP, NC)), mk(g["pt"], (NP, NT))
+    binz = lambda m: (m != 0).astype(np.float32)
+    apa = binz(A_P @ A_P.T)
+    apc, apt = binz(A_P @ P_C), binz(A_P @ P_T)
+    feats = sp.csr_matrix((g["feat_data"], g["feat_indices"], g["feat_indptr"]), shape=tuple(g["feat_shape"]))
+    rowsum = np.array(feats.sum(1)).flatten()
+    with np.errstate(divide="ignore"):
+        r_inv = np.power(rowsum, -1.0)
+    r_inv[np.isinf(r_inv)] = 0.0
+    features = torch.from_numpy(np.asarray(sp.diags(r_inv).dot(feats).todense(), dtype=np.float32))
+    return NA, apa, binz(apc @ apc.T), binz(apt @ apt.T), features
+
+
+def _coo_edges(m):
+    c = m.tocoo()
+    return torch.from_numpy(c.row.astype(np.int64)), torch.from_numpy(c.col.astype(np.int64))
+
+
+@pytest.mark.parametrize("tag", ["coded", "named"])
+def test_nc_forward_dblp(tag):
+    fx = load("nc_dblp.npz")
+    NA, apa, apcpa, aptpa, features = _dblp_graphs()
+    assert (apa.nnz, apcpa.nnz, aptpa.nnz) == (11113, 5000495, 7043571)
+    adjs = [_coo_edges(apa)] * 3 if tag == "coded" else [_coo_edges(apa), _coo_edges(apcpa), _coo_edges(aptpa)]
+    s1, s2, tgt = O.nc_forward(adjs, features, T(fx["w_t"]), T(fx["b_t"]), 3)
+    rows = fx["rows"]
+    for nm, o in (("s1", s1), ("s2", s2), ("target", tgt)):
+        assert_rows_close(o[rows], fx[f"{tag}_{nm}_rows"], what=f"{tag} {nm}")
+    tab = O.DiffusionTables(**NC_TABLE)
+    den = O.p_sample(tab, weights_from(fx, "dn_"), s1 + s2, 0)
+    emb = tgt + den
+    assert_rows_close(emb[rows], fx[f"{tag}_allembeds_rows"], what=f"{tag} allembeds")
+    scores = torch.nn.functional.linear(emb, T(fx["w_dense"]), T(fx["b_dense"]))
+    assert_rows_close(scores[rows], fx[f"{tag}_scores_rows"], rtol=2e-5, what=f"{tag} scores")

@@ -1,0 +1,352 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ by running the reference's OWN Model.py.
+
+Run in the build container only (it needs /root/reference, which never travels):
+
+    python tools/make_golden.py            # both programs, one subprocess each
+    python tools/make_golden.py rec|nc     # one of them, in this process
+
+How the reference is run.  Its Model.py files import `dgl` (not installed, no network) for
+exactly three things: dgl.function.copy_u / dgl.function.sum message-passing tags, a graph
+object offering local_scope / out_degrees / in_degrees / ndata / update_all, and (NC only,
+imported but never called) dgl.nn.pytorch.GraphConv.  An in-memory stand-in for those names
+is installed in sys.modules before the import; update_all(copy_u, sum) is
+zeros.index_add_(0, dst, x[src]) -- DGL's documented semantics.  Everything else
+(LeakyReLU, normalize, the diffusion tables, q_sample, Denoise, p_sample, training_losses2,
+cal_loss + backward) is the reference's code, unmodified, on torch CPU.  `params.py` parses
+sys.argv at import, so argv is reset first.  Only OUTPUT tensors (and the synthetic inputs
+that produced them) are written; no reference source is copied.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+
+# --------------------------------------------------------------------------------------
+# dgl stand-in
+# --------------------------------------------------------------------------------------
+class FakeGraph:
+    def __init__(self, src, dst, num_nodes):
+        self.src = torch.as_tensor(np.asarray(src), dtype=torch.long)
+        self.dst = torch.as_tensor(np.asarray(dst), dtype=torch.long)
+        self.n = int(num_nodes)
+        self.ndata = {}
+
+    @contextlib.contextmanager
+    def local_scope(self):
+        saved = dict(self.ndata)
+        try:
+            yield
+        finally:
+            self.ndata = saved
+
+    def out_degrees(self):
+        return torch.bincount(self.src, minlength=self.n)
+
+    def in_degrees(self):
+        return torch.bincount(self.dst, minlength=self.n)
+
+    def update_all(self, message_func, reduce_func):
+        assert message_func[0] == "copy_u" and reduce_func[0] == "sum"
+        x = self.ndata[message_func[1]]
+        self.ndata[reduce_func[2]] = torch.zeros_like(x).index_add_(0, self.dst, x[self.src])
+
+
+def install_dgl_stub():
+    dgl = types.ModuleType("dgl")
+    fn = types.ModuleType("dgl.function")
+    fn.copy_u = lambda u, out: ("copy_u", u, out)
+    fn.sum = lambda msg, out: ("sum", msg, out)
+    nn_mod = types.ModuleType("dgl.nn")
+    nn_pt = types.ModuleType("dgl.nn.pytorch")
+    nn_pt.GraphConv = object
+    dgl.function, dgl.nn, nn_mod.pytorch = fn, nn_mod, nn_pt
+    dgl.graph = lambda data, idtype=None, num_nodes=None: FakeGraph(data[0], data[1], num_nodes)
+    sys.modules.update({"dgl": dgl, "dgl.function": fn, "dgl.nn": nn_mod, "dgl.nn.pytorch": nn_pt})
+
+
+def import_reference(subdir):
+    install_dgl_stub()
+    sys.argv = ["make_golden"]
+    sys.path.insert(0, os.path.join(REF, subdir))
+    import Model  # noqa: the reference's module
+    return Model
+
+
+def np64(t):
+    return t.detach().cpu().numpy()
+
+
+class Recorder:
+    """Captures the tensors torch.randint / torch.randn_like hand to the reference."""
+
+    def __init__(self):
+        self.randint, self.randn = [], []
+
+    def __enter__(self):
+        self._ri, self._rn = torch.randint, torch.randn_like
+
+        def ri(*a, **k):
+            out = self._ri(*a, **k)
+            self.randint.append(out.clone())
+            return out
+
+        def rn(*a, **k):
+            out = self._rn(*a, **k)
+            self.randn.append(out.clone())
+            return out
+
+        torch.randint, torch.randn_like = ri, rn
+        return self
+
+    def __exit__(self, *exc):
+        torch.randint, torch.randn_like = self._ri, self._rn
+
+
+# --------------------------------------------------------------------------------------
+# Rec
+# --------------------------------------------------------------------------------------
+def denoiser_state(dn, prefix):
+    return {prefix + "w_emb": np64(dn.emb_layer.weight), prefix + "b_emb": np64(dn.emb_layer.bias),
+            prefix + "w_in": np64(dn.in_layers[0].weight), prefix + "b_in": np64(dn.in_layers[0].bias),
+            prefix + "w_out": np64(dn.out_layers[0].weight), prefix + "b_out": np64(dn.out_layers[0].bias)}
+
+
+def build_rec_model(Model, wl, seed):
+    from diffgraph_amd import data as dgdata
+    nu, ni = wl.n_user, wl.n_item
+    mk = lambda ui: FakeGraph(*dgdata.bipartite_edges(ui[0], ui[1], nu), nu + ni)
+    handler = types.SimpleNamespace(userNum=nu, itemNum=ni, target_adj=mk(wl.target),
+                                    behavior_mats=[mk(b) for b in wl.behaviours])
+    torch.manual_seed(seed)
+    model = Model.HGDM(handler)
+    model.eval()  # dropout off: parity runs are deterministic
+    ue = torch.from_numpy(dgdata.xavier_uniform(nu, 64, seed=0))
+    ie = torch.from_numpy(dgdata.xavier_uniform(ni, 64, seed=1))
+    with torch.no_grad():
+        model.embedding_dict["user_emb"].copy_(ue)
+        model.embedding_dict["item_emb"].copy_(ie)
+    return model, handler
+
+
+def gen_rec():
+    Model = import_reference("DiffGraph-Rec")
+    from diffgraph_amd import data as dgdata
+
+    # ---------- tiny graph: full tensors for every function on the path ----------
+    wl = dgdata.rec_workload("tiny")
+    model, handler = build_rec_model(Model, wl, seed=7)
+    nu, ni = wl.n_user, wl.n_item
+    fx = {"n_user": nu, "n_item": ni,
+          "target_u": wl.target[0], "target_i": wl.target[1]}
+    for k, b in enumerate(wl.behaviours):
+        fx[f"beh{k}_u"], fx[f"beh{k}_i"] = b
+    ue, ie = model.embedding_dict["user_emb"], model.embedding_dict["item_emb"]
+    fx["user_emb"], fx["item_emb"] = np64(ue), np64(ie)
+    with torch.no_grad():
+        fx["layer_y"] = np64(model.layers[0](handler.target_adj, ue, ie))                 # a1
+        tu, ti, hu, hi = model.forward()                                                    # a2
+        fx["fwd_tu"], fx["fwd_ti"], fx["fwd_hu"], fx["fwd_hi"] = map(np64, (tu, ti, hu, hi))
+        dp = model.diffusion_process
+        for nm in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",        # a5
+                   "sqrt_one_minus_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                   "posterior_mean_coef1", "posterior_mean_coef2"):
+            fx["tab_" + nm] = np64(getattr(dp, nm))
+        fx.update(denoiser_state(model.usr_denoiser, "usr_"))
+        fx.update(denoiser_state(model.item_denoiser, "item_"))
+        g = torch.Generator().manual_seed(11)
+        t_q = torch.randint(0, 200, (nu,), generator=g)
+        t_q[:4] = torch.tensor([0, 1, 199, 100])
+        noise_q = torch.randn(nu, 64, generator=g)
+        fx["q_t"], fx["q_noise"] = np64(t_q), np64(noise_q)
+        fx["q_out"] = np64(dp.q_sample(hu, t_q, noise_q))                                   # a6
+        for tv in (0, 1, 50, 199):                                                          # a7
+            fx[f"dn_out_t{tv}"] = np64(model.usr_denoiser(hu, torch.full((nu,), tv), False))
+        fx["dn_out_mixed"] = np64(model.usr_denoiser(hu, t_q, False))
+        # a8: p_sample(steps=0) with intermediates, by wrapping p_mean_variance
+        kept = {}
+        orig = dp.p_mean_variance
+
+        def spy(m, x, t):
+            mean, lv = orig(m, x, t)
+            if int(t[0]) in (199, 100, 1):
+                kept[int(t[0])] = mean.clone()
+            return mean, lv
+
+        dp.p_mean_variance = spy
+        fx["ps_usr_x0"] = np64(dp.p_sample(model.usr_denoiser, hu, 0))
+        for k, v in kept.items():
+            fx[f"ps_usr_after{k}"] = np64(v)
+        dp.p_mean_variance = orig
+        fx["ps_item_x0"] = np64(dp.p_sample(model.item_denoiser, hi, 0))
+        # a8 with sampling_steps > 0: the start point is q_sample(x, steps-1, fresh noise)
+        with Recorder() as rec:
+            torch.manual_seed(5)
+            fx["ps5_usr_x0"] = np64(dp.p_sample(model.usr_denoiser, hu, 5))
+        fx["ps5_noise"] = np64(rec.randn[0])
+        # a9: training_losses2 with recorded draws
+        batch = torch.tensor([0, 3, 3, 17, nu - 1, 5, 9, 9], dtype=torch.long)
+        with Recorder() as rec:
+            torch.manual_seed(13)
+            loss, out = dp.training_losses2(model.usr_denoiser, tu, hu, batch)
+        fx["tl_ts"], fx["tl_noise"], fx["tl_batch"] = np64(rec.randint[0]), np64(rec.randn[0]), np64(batch)
+        fx["tl_loss"], fx["tl_out"] = np64(loss), np64(out)
+        fx["predict_u"], fx["predict_i"] = map(np64, model.predict())                       # a10 glue
+    # a11: cal_loss + backward
+    g = torch.Generator().manual_seed(17)
+    B = 64
+    ancs = torch.randint(0, nu, (B,), generator=g)
+    poss = torch.randint(0, ni, (B,), generator=g)
+    negs = torch.randint(0, ni, (B,), generator=g)
+    model.zero_grad()
+    with Recorder() as rec:
+        torch.manual_seed(19)
+        loss, bpr, reg, diff = model.cal_loss(ancs, poss, negs)
+    loss.backward()
+    fx["cl_ancs"], fx["cl_poss"], fx["cl_negs"] = np64(ancs), np64(poss), np64(negs)
+    fx["cl_ts_u"], fx["cl_ts_i"] = np64(rec.randint[0]), np64(rec.randint[1])
+    fx["cl_noise_u"], fx["cl_noise_i"] = np64(rec.randn[0]), np64(rec.randn[1])
+    fx["cl_losses"] = np.array([loss.item(), bpr.item(), reg.item(), diff.item()], dtype=np.float64)
+    fx["cl_batch_div"] = np.array([Model.args.batch, Model.args.reg], dtype=np.float64)
+    fx["cl_grad_user"], fx["cl_grad_item"] = np64(ue.grad), np64(ie.grad)
+    for pre, dn in (("usr_", model.usr_denoiser), ("item_", model.item_denoiser)):
+        fx["cl_grad_" + pre + "w_emb"] = np64(dn.emb_layer.weight.grad)
+        fx["cl_grad_" + pre + "b_emb"] = np64(dn.emb_layer.bias.grad)
+        fx["cl_grad_" + pre + "w_in"] = np64(dn.in_layers[0].weight.grad)
+        fx["cl_grad_" + pre + "b_in"] = np64(dn.in_layers[0].bias.grad)
+        fx["cl_grad_" + pre + "w_out"] = np64(dn.out_layers[0].weight.grad)
+        fx["cl_grad_" + pre + "b_out"] = np64(dn.out_layers[0].bias.grad)
+    np.savez_compressed(os.path.join(OUT, "rec_tiny.npz"), **fx)
+    print("rec_tiny.npz:", len(fx), "arrays")
+
+    # ---------- Retail-Rocket-shaped graph: sampled rows + fp64 column sums ----------
+    wl = dgdata.rec_workload("retail_rocket")
+    model, handler = build_rec_model(Model, wl, seed=7)
+    rows_u = np.sort(np.random.default_rng(3).choice(wl.n_user, 256, replace=False))
+    rows_i = np.sort(np.random.default_rng(4).choice(wl.n_item, 256, replace=False))
+    fx = {"rows_u": rows_u, "rows_i": rows_i}
+    with torch.no_grad():
+        outs = model.forward()
+        for nm, o, rows in zip(("tu", "ti", "hu", "hi"), outs, (rows_u, rows_i, rows_u, rows_i)):
+            fx["fwd_" + nm + "_rows"] = np64(o)[rows]
+            fx["fwd_" + nm + "_colsum"] = np64(o).astype(np.float64).sum(0)
+            fx["fwd_" + nm + "_abssum"] = np.abs(np64(o).astype(np.float64)).sum(0)
+        fx.update(denoiser_state(model.usr_denoiser, "usr_"))
+        fx.update(denoiser_state(model.item_denoiser, "item_"))
+        pu, pi = model.predict()
+        fx["predict_u_rows"], fx["predict_i_rows"] = np64(pu)[rows_u], np64(pi)[rows_i]
+        fx["predict_u_colsum"] = np64(pu).astype(np.float64).sum(0)
+        fx["predict_i_colsum"] = np64(pi).astype(np.float64).sum(0)
+    np.savez_compressed(os.path.join(OUT, "rec_retail_rocket.npz"), **fx)
+    print("rec_retail_rocket.npz:", len(fx), "arrays")
+
+
+# --------------------------------------------------------------------------------------
+# NC (DBLP)
+# --------------------------------------------------------------------------------------
+def load_dblp():
+    """Restates the ~30 data-loading lines of DiffGraph_NC/DataHandler.py:208-259 that the
+    model needs (features, six raw relations); sklearn's removed OneHotEncoder(sparse=...)
+    argument keeps the reference's own loader from running."""
+    import scipy.sparse as sp
+    d = os.path.join(REF, "DiffGraph_NC", "data", "DBLP")
+    feats = sp.load_npz(os.path.join(d, "a_feat.npz")).astype("float32")
+    edges = {k: np.loadtxt(os.path.join(d, k + ".txt"), dtype=int) for k in ("ap", "pa", "cp", "pc", "pt", "tp")}
+    labels = np.load(os.path.join(d, "labels.npy"))
+    return feats, edges, labels
+
+
+def gen_nc():
+    Model = import_reference("DiffGraph_NC")
+    import scipy.sparse as sp
+    feats, edges, labels = load_dblp()
+    NA = feats.shape[0]
+    ap, pa, cp, pc, pt, tp = (edges[k] for k in ("ap", "pa", "cp", "pc", "pt", "tp"))
+    NP = max(ap[:, 1].max(), pa[:, 0].max()) + 1
+    NC = max(cp[:, 0].max(), pc[:, 1].max()) + 1
+    NT = max(pt[:, 1].max(), tp[:, 0].max()) + 1
+    # graph inputs shipped to the GPU box as plain arrays (public DBLP edge lists / features)
+    fcsr = feats.tocsr()
+    np.savez_compressed(os.path.join(OUT, "dblp_graph.npz"), ap=ap.astype(np.int32), pc=pc.astype(np.int32),
+                        pt=pt.astype(np.int32), feat_data=fcsr.data.astype(np.float32),
+                        feat_indices=fcsr.indices.astype(np.int32), feat_indptr=fcsr.indptr.astype(np.int32),
+                        feat_shape=np.array(fcsr.shape), labels=labels.astype(np.int64),
+                        counts=np.array([NA, NP, NC, NT]))
+    # row-normalised features (preprocess_features, DataHandler.py:254-259)
+    rowsum = np.array(feats.sum(1)).flatten()
+    r_inv = np.power(rowsum, -1).flatten()
+    r_inv[np.isinf(r_inv)] = 0.0
+    features = torch.FloatTensor(np.asarray(sp.diags(r_inv).dot(feats).todense()))
+
+    A_P = sp.coo_matrix((np.ones(len(ap)), (ap[:, 0], ap[:, 1])), shape=(NA, NP)).tocsr()
+    P_C = sp.coo_matrix((np.ones(len(pc)), (pc[:, 0], pc[:, 1])), shape=(NP, NC)).tocsr()
+    P_T = sp.coo_matrix((np.ones(len(pt)), (pt[:, 0], pt[:, 1])), shape=(NP, NT)).tocsr()
+    binz = lambda m: (m != 0).astype(np.float32)
+    apa = binz(A_P @ A_P.T)
+    apc = binz(A_P @ P_C)
+    apcpa = binz(apc @ apc.T)
+    apt = binz(A_P @ P_T)
+    aptpa = binz(apt @ apt.T)
+    print("APA/APCPA/APTPA nnz:", apa.nnz, apcpa.nnz, aptpa.nnz)
+
+    def fg(m):
+        coo = m.tocoo()
+        return FakeGraph(coo.row, coo.col, NA)
+
+    torch.manual_seed(23)
+    model = Model.HGDM(features.shape[1])
+    model.eval()
+    rows = np.sort(np.random.default_rng(6).choice(NA, 256, replace=False))
+    fx = {"rows": rows, "w_t": np64(model.transform_layer.weight), "b_t": np64(model.transform_layer.bias),
+          "w_dense": np64(model.dense.weight), "b_dense": np64(model.dense.bias)}
+    fx.update(denoiser_state(model.user_denoise_model, "dn_"))
+    dm = model.diffusion_model
+    for nm in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+               "posterior_mean_coef1", "posterior_mean_coef2"):
+        fx["tab_" + nm] = np64(getattr(dm, nm))
+    with torch.no_grad():
+        # "as coded": the three channels are the identical APA graph (all softmax weights > 0)
+        for tag, adjs in (("coded", [fg(apa), fg(apa), fg(apa)]), ("named", [fg(apa), fg(apcpa), fg(aptpa)])):
+            s1, s2, tgt = model.forward(adjs, features)
+            for nm, o in (("s1", s1), ("s2", s2), ("target", tgt)):
+                fx[f"{tag}_{nm}_rows"] = np64(o)[rows]
+                fx[f"{tag}_{nm}_colsum"] = np64(o).astype(np.float64).sum(0)
+            emb, scores = model.get_allembeds(adjs, features)
+            fx[f"{tag}_allembeds_rows"] = np64(emb)[rows]
+            fx[f"{tag}_scores_rows"] = np64(scores)[rows]
+            fx[f"{tag}_allembeds_colsum"] = np64(emb).astype(np.float64).sum(0)
+        # cal_loss forward values with recorded draws (as-coded graphs)
+        adjs = [fg(apa), fg(apa), fg(apa)]
+        onehot = torch.zeros(NA, 4)
+        onehot[torch.arange(NA), torch.from_numpy(labels).long()] = 1.0
+        ancs = torch.tensor([3, 17, 200, 1024, 4056, 5, 8, 13])
+        with Recorder() as rec:
+            torch.manual_seed(29)
+            nll, diff = model.cal_loss(ancs, onehot, adjs, features)
+        fx["cl_ancs"], fx["cl_ts"], fx["cl_noise"] = np64(ancs), np64(rec.randint[0]), np64(rec.randn[0])
+        fx["cl_losses"] = np.array([nll.item(), diff.item()], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "nc_dblp.npz"), **fx)
+    print("nc_dblp.npz:", len(fx), "arrays")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["rec", "nc"]
+    if len(which) == 1:
+        {"rec": gen_rec, "nc": gen_nc}[which[0]]()
+    else:
+        for w in which:  # the two programs share module names (Model, params, Utils): one process each
+            subprocess.run([sys.executable, os.path.abspath(__file__), w], check=True)
