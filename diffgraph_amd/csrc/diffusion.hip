@@ -266,9 +266,9 @@ extern "C" int dg_time_bias_table(const dg_denoiser *dn, int32_t n_steps, float 
 extern "C" int dg_q_sample(const float *x0, const float *noise, const int64_t *t, const float *sqrt_ac,
                            const float *sqrt_1mac, int32_t n_steps, int64_t n, int32_t d, float *x_t, void *stream) {
   if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_q_sample: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (n == 0) return 0;
   if (!x0 || !noise || !t || !sqrt_ac || !sqrt_1mac || !x_t) return dg_fail(DG_ERR_ARG, "dg_q_sample: NULL argument");
   if (n_steps <= 0 || n < 0) return dg_fail(DG_ERR_ARG, "dg_q_sample: bad sizes");
-  if (n == 0) return 0;
   const int64_t n4 = n * (DG_D / 4);
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -283,6 +283,7 @@ extern "C" int dg_denoise_fwd(const dg_denoiser *dn, const float *time_bias, int
                               const int64_t *t, int64_t n, int32_t d, float *out, void *stream) {
   int rc = check_denoiser("dg_denoise_fwd", dn, time_bias, n_steps, d);
   if (rc) return rc;
+  if (n == 0) return 0;
   if (!x || !t || !out || n < 0) return dg_fail(DG_ERR_ARG, "dg_denoise_fwd: NULL argument");
   dn_task k = {};
   k.w_in = dn->w_in; k.w_out = dn->w_out; k.b_out = dn->b_out; k.time_bias = time_bias;
@@ -294,6 +295,7 @@ extern "C" int dg_p_sample_loop(const dg_denoiser *dn, const float *time_bias, c
                                 int32_t n_steps, const float *x_T, int64_t n, int32_t d, float *x_0, void *stream) {
   int rc = check_denoiser("dg_p_sample_loop", dn, time_bias, n_steps, d);
   if (rc) return rc;
+  if (n == 0) return 0;
   if (!coef1 || !coef2 || !x_T || !x_0 || n < 0) return dg_fail(DG_ERR_ARG, "dg_p_sample_loop: NULL argument");
   dn_task k = {};
   k.w_in = dn->w_in; k.w_out = dn->w_out; k.b_out = dn->b_out; k.time_bias = time_bias;
@@ -307,6 +309,7 @@ extern "C" int dg_diffusion_loss_fwd(const dg_denoiser *dn, const float *time_bi
                                      double *row_loss, float *x_t_out, void *stream) {
   int rc = check_denoiser("dg_diffusion_loss_fwd", dn, time_bias, n_steps, d);
   if (rc) return rc;
+  if (n == 0) return 0;
   if (!target || !x_start || !ts || !loss_w || !out || !row_loss || n < 0)
     return dg_fail(DG_ERR_ARG, "dg_diffusion_loss_fwd: NULL argument");
   if ((sqrt_ac != nullptr) != (sqrt_1mac != nullptr) || (sqrt_ac && !noise))

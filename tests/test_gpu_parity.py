@@ -160,7 +160,10 @@ def test_tables_match_reference():
     gd = dg.GaussianDiffusion(**REC_TABLE)
     for nm in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
                "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
-        np.testing.assert_array_equal(getattr(gd, nm).numpy(), fx["tab_" + nm], err_msg=nm)
+        # fp64 host arithmetic may differ in the last bit between host CPUs (vectorised sqrt/log);
+        # what the kernels consume is the fp32 cast, which must be identical
+        np.testing.assert_allclose(getattr(gd, nm).numpy(), fx["tab_" + nm], rtol=4e-16, atol=0, err_msg=nm)
+        np.testing.assert_array_equal(getattr(gd, nm).numpy().astype(np.float32), fx["tab_" + nm].astype(np.float32), err_msg=nm)
 
 
 def test_q_sample_golden():
