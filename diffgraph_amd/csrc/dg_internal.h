@@ -26,11 +26,16 @@ int dg_fail(int code, const char *fmt, ...);
 struct dg_csr {
   int32_t *rowptr = nullptr;     // [n+1]
   int32_t *colidx = nullptr;     // [nnz], ascending inside a row
+  float *colscale = nullptr;     // [nnz] degree norm of the gathered node colidx[p]
   int32_t *row_order = nullptr;  // [n]: hub rows, then wave rows, then group rows (each by falling degree)
-  int32_t *hub_segptr = nullptr; // [n_hub+1] first slab row of each hub row (row_order order)
-  int32_t *seg_row = nullptr;    // [n_seg] hub ordinal of each segment
-  int32_t *seg_begin = nullptr;  // [n_seg] first colidx position of the segment
-  int32_t *seg_end = nullptr;    // [n_seg]
+  // Group rows, in schedule order, 16 words each: words 0..12 the first 13 neighbour ids
+  // (-1 = none), word 13 the row id, word 14 its degree, word 15 the colidx position of
+  // neighbour 13.  One coalesced 64-B read gives a short row everything it needs.
+  int32_t *head = nullptr;       // [n_group][16]
+  float *head_scale = nullptr;   // [n_group][16] norms of the 13 head neighbours
+  int32_t *wave_desc = nullptr;  // [n_wave][4] row, colidx begin, colidx end, 0
+  int32_t *hub_desc = nullptr;   // [n_hub][4] row, first slab row, last slab row + 1, 0
+  int32_t *seg_desc = nullptr;   // [n_seg][2] colidx begin, end of each hub-row segment
   int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0;
 };
 
@@ -49,9 +54,8 @@ struct dg_graph {
 
 // Device-visible description of one graph's share of a batched layer launch.
 struct dg_task_dev {
-  const int32_t *rowptr, *colidx, *row_order, *hub_segptr;
-  const int32_t *seg_row, *seg_begin, *seg_end;
-  const float *dinv_gather;  // norm of the gathered (column) node
+  const int32_t *colidx, *head, *wave_desc, *hub_desc, *seg_desc;
+  const float *colscale, *head_scale;
   const float *dinv_row;     // norm of the receiving (row) node
   const float *dinv_out;     // norm applied by DG_OUT_PRESCALE (the row node's norm as a future source)
   const float *x;
@@ -63,7 +67,7 @@ struct dg_task_dev {
   int32_t flags;
   float slope;
   int32_t blk_begin;      // first block of this task in the main launch
-  int32_t seg_blk_begin;  // first block of this task in the hub-partial launch
+  int32_t hub_blk_begin;  // first block of this task in the hub-row reduce launch
 };
 
 struct dg_task_batch {

@@ -30,9 +30,12 @@ extern "C" int dg_version(void) { return 1; }
 
 namespace {
 
+constexpr int kHead = 13;  // neighbour ids carried in a group row's 16-word head
+
 struct HostCsr {
-  std::vector<int32_t> rowptr, colidx, row_order, hub_segptr, seg_row, seg_begin, seg_end;
-  int32_t n_hub = 0, n_wave = 0, n_group = 0;
+  std::vector<int32_t> rowptr, colidx, row_order, head, wave_desc, hub_desc, seg_desc;
+  std::vector<float> colscale, head_scale;
+  int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0;
 };
 
 // CSR over `row` with ascending `col` inside each row: two stable counting sorts
@@ -77,17 +80,35 @@ void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c) {
     else if (d > group_max) c.n_wave++;
     else c.n_group++;
   }
-  c.hub_segptr.assign((size_t)c.n_hub + 1, 0);
-  c.seg_row.clear(); c.seg_begin.clear(); c.seg_end.clear();
+  c.hub_desc.clear(); c.seg_desc.clear(); c.wave_desc.clear();
+  c.n_seg = 0;
   for (int32_t h = 0; h < c.n_hub; ++h) {
     int32_t r = c.row_order[h];
     int32_t b = c.rowptr[r], e = c.rowptr[r + 1];
+    int32_t s0 = c.n_seg;
     for (int32_t p = b; p < e; p += seg_len) {
-      c.seg_row.push_back(h);
-      c.seg_begin.push_back(p);
-      c.seg_end.push_back(std::min(p + seg_len, e));
+      c.seg_desc.push_back(p);
+      c.seg_desc.push_back(std::min(p + seg_len, e));
+      c.n_seg++;
     }
-    c.hub_segptr[h + 1] = (int32_t)c.seg_row.size();
+    c.hub_desc.insert(c.hub_desc.end(), {r, s0, c.n_seg, 0});
+  }
+  for (int32_t k = 0; k < c.n_wave; ++k) {
+    int32_t r = c.row_order[c.n_hub + k];
+    c.wave_desc.insert(c.wave_desc.end(), {r, c.rowptr[r], c.rowptr[r + 1], 0});
+  }
+  c.head.assign((size_t)c.n_group * 16, -1);
+  c.head_scale.assign((size_t)c.n_group * 16, 0.f);
+  for (int32_t k = 0; k < c.n_group; ++k) {
+    int32_t r = c.row_order[c.n_hub + c.n_wave + k];
+    int32_t b = c.rowptr[r], d = c.rowptr[r + 1] - b;
+    int32_t *hd = &c.head[(size_t)k * 16];
+    float *hs = &c.head_scale[(size_t)k * 16];
+    for (int32_t j = 0; j < std::min(d, kHead); ++j) {
+      hd[j] = c.colidx[b + j];
+      hs[j] = c.colscale[b + j];
+    }
+    hd[13] = r; hd[14] = d; hd[15] = b + kHead;
   }
 }
 
@@ -105,19 +126,21 @@ hipError_t upload_csr(const HostCsr &h, dg_csr &d) {
   hipError_t e;
   if ((e = upload(h.rowptr, &d.rowptr)) != hipSuccess) return e;
   if ((e = upload(h.colidx, &d.colidx)) != hipSuccess) return e;
+  if ((e = upload(h.colscale, &d.colscale)) != hipSuccess) return e;
   if ((e = upload(h.row_order, &d.row_order)) != hipSuccess) return e;
-  if ((e = upload(h.hub_segptr, &d.hub_segptr)) != hipSuccess) return e;
-  if ((e = upload(h.seg_row, &d.seg_row)) != hipSuccess) return e;
-  if ((e = upload(h.seg_begin, &d.seg_begin)) != hipSuccess) return e;
-  if ((e = upload(h.seg_end, &d.seg_end)) != hipSuccess) return e;
-  d.n_hub = h.n_hub; d.n_wave = h.n_wave; d.n_group = h.n_group;
-  d.n_seg = (int32_t)h.seg_row.size();
+  if ((e = upload(h.head, &d.head)) != hipSuccess) return e;
+  if ((e = upload(h.head_scale, &d.head_scale)) != hipSuccess) return e;
+  if ((e = upload(h.wave_desc, &d.wave_desc)) != hipSuccess) return e;
+  if ((e = upload(h.hub_desc, &d.hub_desc)) != hipSuccess) return e;
+  if ((e = upload(h.seg_desc, &d.seg_desc)) != hipSuccess) return e;
+  d.n_hub = h.n_hub; d.n_wave = h.n_wave; d.n_group = h.n_group; d.n_seg = h.n_seg;
   return hipSuccess;
 }
 
 void free_csr(dg_csr &d) {
-  (void)hipFree(d.rowptr); (void)hipFree(d.colidx); (void)hipFree(d.row_order); (void)hipFree(d.hub_segptr);
-  (void)hipFree(d.seg_row); (void)hipFree(d.seg_begin); (void)hipFree(d.seg_end);
+  (void)hipFree(d.rowptr); (void)hipFree(d.colidx); (void)hipFree(d.colscale); (void)hipFree(d.row_order);
+  (void)hipFree(d.head); (void)hipFree(d.head_scale); (void)hipFree(d.wave_desc); (void)hipFree(d.hub_desc);
+  (void)hipFree(d.seg_desc);
   d = dg_csr();
 }
 
@@ -147,8 +170,6 @@ extern "C" int dg_graph_create(int32_t n, int64_t nnz, const int32_t *src, const
   build_csr(n, nnz, dst, src, f);  // rows = destinations
   build_csr(n, nnz, src, dst, b);  // rows = sources
   const bool symmetric = (f.rowptr == b.rowptr) && (f.colidx == b.colidx);
-  build_schedule(n, group_max, seg_len, f);
-  if (!symmetric) build_schedule(n, group_max, seg_len, b);
 
   // clamp(min=1), pow(-0.5) in fp32: torch's CPU path evaluates pow(x,-0.5) as 1/sqrt(x)
   // with correctly rounded sqrt and divide, which is what this does.
@@ -158,6 +179,14 @@ extern "C" int dg_graph_create(int32_t n, int64_t nnz, const int32_t *src, const
     int32_t out_deg = b.rowptr[i + 1] - b.rowptr[i];
     ddst[i] = 1.0f / sqrtf((float)std::max(in_deg, 1));
     dsrc[i] = 1.0f / sqrtf((float)std::max(out_deg, 1));
+  }
+  f.colscale.resize((size_t)nnz);
+  for (int64_t p = 0; p < nnz; ++p) f.colscale[(size_t)p] = dsrc[f.colidx[(size_t)p]];  // gathered node = a source
+  build_schedule(n, group_max, seg_len, f);
+  if (!symmetric) {
+    b.colscale.resize((size_t)nnz);
+    for (int64_t p = 0; p < nnz; ++p) b.colscale[(size_t)p] = ddst[b.colidx[(size_t)p]];
+    build_schedule(n, group_max, seg_len, b);
   }
 
   dg_graph *g = new dg_graph();

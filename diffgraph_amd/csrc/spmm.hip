@@ -15,8 +15,11 @@
 //   wave rows  (deg <= seg_len)  : the four groups of a wavefront take every fourth chunk
 //                                  of 16 neighbours, then add their sums;
 //   hub rows   (deg >  seg_len)  : cut into seg_len-neighbour segments summed by separate
-//                                  wavefronts into a slab (first launch); the row's own
-//                                  wavefront then adds the slab rows in order.
+//                                  wavefronts of the same launch into a slab; a second,
+//                                  small launch adds each hub row's slab rows in order.
+// A group row's first 13 neighbour ids, its row id and degree sit in one 64-B head record
+// (graph.hip), and every edge carries the gathered node's degree norm next to its id, so
+// the dependent-load chain of a short row is: head -> neighbour rows -> store.
 // Every sum has a fixed order, so results are bitwise reproducible run to run.
 // Neighbour gathers go through a buffer descriptor: the id -1 of a padding slot turns
 // into an out-of-range offset, which the hardware answers with zeros and no memory access.
@@ -60,19 +63,19 @@ __device__ __forceinline__ void gather4(__amdgpu_buffer_rsrc_t xr, int c, float 
   acc += v0; acc += v1; acc += v2; acc += v3;
 }
 
-// Sum of the table rows listed in colidx[p .. end) taken 16 at a time with stride `stride`
+// Adds the table rows listed in colidx[p .. end), taken 16 at a time with stride `stride`
 // between chunks (16: the group owns the whole list; 64: four groups interleave).
 // INDEXED = false reads rows p, p+1, ... themselves (slab rows of a hub row).
 template <bool INDEXED, bool SCALE>
-__device__ __forceinline__ f32x4 gather_rows(__amdgpu_buffer_rsrc_t xr, const int32_t *__restrict__ colidx,
-                                             const float *__restrict__ dinv, int p, int end, int stride, int l) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void gather_rows(__amdgpu_buffer_rsrc_t xr, const int32_t *__restrict__ colidx,
+                                            const float *__restrict__ colscale, int p, int end, int stride, int l,
+                                            f32x4 &acc) {
   const unsigned lane_off = (unsigned)l * 16u;
   int c = -1;
   float s = 0.f;
   if (p + l < end) {
     c = INDEXED ? colidx[p + l] : p + l;
-    if (SCALE) s = dinv[c];
+    if (SCALE) s = colscale[p + l];
   }
   while (p < end) {
     const int pn = p + stride;
@@ -80,7 +83,7 @@ __device__ __forceinline__ f32x4 gather_rows(__amdgpu_buffer_rsrc_t xr, const in
     float sn = 0.f;
     if (pn + l < end) {  // next chunk's ids (and norms) are in flight while this chunk's rows load
       cn = INDEXED ? colidx[pn + l] : pn + l;
-      if (SCALE) sn = dinv[cn];
+      if (SCALE) sn = colscale[pn + l];
     }
     const int cnt = end - p;
     gather4<0, SCALE>(xr, c, s, lane_off, acc);
@@ -89,7 +92,6 @@ __device__ __forceinline__ f32x4 gather_rows(__amdgpu_buffer_rsrc_t xr, const in
     if (cnt > 12) gather4<12, SCALE>(xr, c, s, lane_off, acc);
     c = cn; s = sn; p = pn;
   }
-  return acc;
 }
 
 __device__ __forceinline__ f32x4 add_groups(f32x4 v) {  // (g0+g1)+(g2+g3), same value in every group
@@ -108,11 +110,26 @@ __device__ __forceinline__ float sum16(float v) {
   return v;
 }
 
+// What the epilogue needs from memory; asked for before the neighbour rows so that it
+// arrives while they load.
+struct row_ctx {
+  float di, dout;
+  f32x4 a_in;
+};
+
+__device__ __forceinline__ row_ctx load_row_ctx(const dg_task_dev &T, int row, int l) {
+  row_ctx c;
+  c.di = T.dinv_row[row];
+  c.dout = (T.flags & DG_OUT_PRESCALE) ? T.dinv_out[row] : 1.0f;
+  c.a_in = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (T.acc_out) c.a_in = reinterpret_cast<const f32x4 *>(T.acc_in)[(size_t)row * (DG_D / 4) + l];
+  return c;
+}
+
 // rst*norm, LeakyReLU, F.normalize, layer sum, next layer's input (Model.py:165-172,67-70).
-__device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, f32x4 acc, int l) {
-  const float di = T.dinv_row[row];
+__device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const row_ctx &rc, f32x4 acc, int l) {
   const float slope = T.slope;
-  f32x4 y = acc * di;
+  f32x4 y = acc * rc.di;
   y.x = y.x > 0.f ? y.x : y.x * slope;
   y.y = y.y > 0.f ? y.y : y.y * slope;
   y.z = y.z > 0.f ? y.z : y.z * slope;
@@ -125,78 +142,85 @@ __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, f32x4 ac
     const float den = fmaxf(sqrtf(ss), 1e-12f);
     yn = y / den;
   }
-  if (T.acc_out) {
-    f32x4 a = reinterpret_cast<const f32x4 *>(T.acc_in)[o];
-    reinterpret_cast<f32x4 *>(T.acc_out)[o] = a + yn;
-  }
+  if (T.acc_out) reinterpret_cast<f32x4 *>(T.acc_out)[o] = rc.a_in + yn;
   if (T.e_out) {
     f32x4 e = (T.flags & DG_OUT_NORM) ? yn : y;
-    if (T.flags & DG_OUT_PRESCALE) e *= T.dinv_out[row];
+    if (T.flags & DG_OUT_PRESCALE) e *= rc.dout;
     reinterpret_cast<f32x4 *>(T.e_out)[o] = e;
   }
 }
 
+// Blocks of one task, longest work first: hub-row segments (one wavefront each, partial
+// sums into the slab), wave rows, group rows.
 template <bool SCALE>
 __device__ __forceinline__ void layer_block(const dg_task_dev &T, int lb) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l = lane & 15;
-  const int nb_hub = (T.n_hub + 3) >> 2, nb_wave = (T.n_wave + 3) >> 2;
-  if (lb < nb_hub) {
-    const int h = lb * 4 + wave;
-    if (h < T.n_hub) {
-      const int row = T.row_order[h];
-      const int s0 = T.hub_segptr[h], s1 = T.hub_segptr[h + 1];
-      f32x4 acc = gather_rows<false, false>(table_rsrc(T.slab, T.n_seg), nullptr, nullptr, s0 + 16 * q, s1, 64, l);
+  const int nb_seg = (T.n_seg + 3) >> 2, nb_wave = (T.n_wave + 3) >> 2;
+  const __amdgpu_buffer_rsrc_t xr = table_rsrc(T.x, T.n);
+  if (lb < nb_seg) {
+    const int s = lb * 4 + wave;
+    if (s < T.n_seg) {
+      const int p = T.seg_desc[2 * s], e = T.seg_desc[2 * s + 1];
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      gather_rows<true, SCALE>(xr, T.colidx, T.colscale, p + 16 * q, e, 64, l, acc);
       acc = add_groups(acc);
-      if (q == 0) epilogue(T, row, acc, l);
+      if (q == 0) reinterpret_cast<f32x4 *>(T.slab)[(size_t)s * (DG_D / 4) + l] = acc;
     }
-  } else if (lb < nb_hub + nb_wave) {
-    const int k = (lb - nb_hub) * 4 + wave;
+  } else if (lb < nb_seg + nb_wave) {
+    const int k = (lb - nb_seg) * 4 + wave;
     if (k < T.n_wave) {
-      const int row = T.row_order[T.n_hub + k];
-      const int b = T.rowptr[row], e = T.rowptr[row + 1];
-      f32x4 acc = gather_rows<true, SCALE>(table_rsrc(T.x, T.n), T.colidx, T.dinv_gather, b + 16 * q, e, 64, l);
+      const int4 d = reinterpret_cast<const int4 *>(T.wave_desc)[k];
+      const row_ctx rc = load_row_ctx(T, d.x, l);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      gather_rows<true, SCALE>(xr, T.colidx, T.colscale, d.y + 16 * q, d.z, 64, l, acc);
       acc = add_groups(acc);
-      if (q == 0) epilogue(T, row, acc, l);
+      if (q == 0) epilogue(T, d.x, rc, acc, l);
     }
   } else {
-    const int k = (lb - nb_hub - nb_wave) * 16 + wave * 4 + q;
+    const int k = (lb - nb_seg - nb_wave) * 16 + wave * 4 + q;
     if (k < T.n_group) {
-      const int row = T.row_order[T.n_hub + T.n_wave + k];
-      const int b = T.rowptr[row], e = T.rowptr[row + 1];
-      f32x4 acc = gather_rows<true, SCALE>(table_rsrc(T.x, T.n), T.colidx, T.dinv_gather, b, e, 16, l);
-      epilogue(T, row, acc, l);
+      const int hv = T.head[(size_t)k * 16 + l];
+      const float hs = SCALE ? T.head_scale[(size_t)k * 16 + l] : 0.f;
+      const int row = bcast16<13>(hv), deg = bcast16<14>(hv), tail = bcast16<15>(hv);
+      const row_ctx rc = load_row_ctx(T, row, l);
+      const int c = l < 13 ? hv : -1;
+      const unsigned lane_off = (unsigned)l * 16u;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      gather4<0, SCALE>(xr, c, hs, lane_off, acc);
+      if (deg > 4) gather4<4, SCALE>(xr, c, hs, lane_off, acc);
+      if (deg > 8) gather4<8, SCALE>(xr, c, hs, lane_off, acc);
+      if (deg > 12) gather4<12, SCALE>(xr, c, hs, lane_off, acc);
+      if (deg > 13) gather_rows<true, SCALE>(xr, T.colidx, T.colscale, tail, tail + deg - 13, 16, l, acc);
+      epilogue(T, row, rc, acc, l);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void gcn_layer_kernel(const dg_task_batch batch) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ const dg_task_dev &find_task(const dg_task_batch &batch, int b, bool hub) {
   int ti = 0;
   for (int k = 1; k < batch.n_tasks; ++k)
-    if (b >= batch.t[k].blk_begin) ti = k;
-  const dg_task_dev &T = batch.t[ti];
-  if (T.flags & DG_IN_PRESCALED) layer_block<false>(T, b - T.blk_begin);
-  else layer_block<true>(T, b - T.blk_begin);
+    if (b >= (hub ? batch.t[k].hub_blk_begin : batch.t[k].blk_begin)) ti = k;
+  return batch.t[ti];
 }
 
-// Partial sums of hub-row segments: one wavefront per segment -> slab[segment][64].
-__global__ __launch_bounds__(256) void hub_partial_kernel(const dg_task_batch batch) {
-  const int b = blockIdx.x;
-  int ti = 0;
-  for (int k = 1; k < batch.n_tasks; ++k)
-    if (b >= batch.t[k].seg_blk_begin) ti = k;
-  const dg_task_dev &T = batch.t[ti];
+__global__ __launch_bounds__(256) void gcn_layer_kernel(const dg_task_batch batch) {
+  const dg_task_dev &T = find_task(batch, blockIdx.x, false);
+  if (T.flags & DG_IN_PRESCALED) layer_block<false>(T, blockIdx.x - T.blk_begin);
+  else layer_block<true>(T, blockIdx.x - T.blk_begin);
+}
+
+// Hub rows: one wavefront per row adds the row's slab rows in order, then the epilogue.
+__global__ __launch_bounds__(256) void hub_reduce_kernel(const dg_task_batch batch) {
+  const dg_task_dev &T = find_task(batch, blockIdx.x, true);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l = lane & 15;
-  const int s = (b - T.seg_blk_begin) * 4 + wave;
-  if (s >= T.n_seg) return;
-  const int p = T.seg_begin[s], e = T.seg_end[s];
-  f32x4 acc;
-  if (T.flags & DG_IN_PRESCALED)
-    acc = gather_rows<true, false>(table_rsrc(T.x, T.n), T.colidx, T.dinv_gather, p + 16 * q, e, 64, l);
-  else
-    acc = gather_rows<true, true>(table_rsrc(T.x, T.n), T.colidx, T.dinv_gather, p + 16 * q, e, 64, l);
+  const int h = (blockIdx.x - T.hub_blk_begin) * 4 + wave;
+  if (h >= T.n_hub) return;
+  const int4 d = reinterpret_cast<const int4 *>(T.hub_desc)[h];
+  const row_ctx rc = load_row_ctx(T, d.x, l);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  gather_rows<false, false>(table_rsrc(T.slab, T.n_seg), nullptr, nullptr, d.y + 16 * q, d.z, 64, l, acc);
   acc = add_groups(acc);
-  if (q == 0) reinterpret_cast<f32x4 *>(T.slab)[(size_t)s * (DG_D / 4) + l] = acc;
+  if (q == 0) epilogue(T, d.x, rc, acc, l);
 }
 
 struct sum_args {
@@ -221,11 +245,10 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   if (!in.e_out && !in.acc_out) return dg_fail(DG_ERR_ARG, "layer task: no output requested");
   if (in.e_out == in.x) return dg_fail(DG_ERR_ARG, "layer task: e_out must not alias x");
   const dg_csr &c = transpose ? g->bwd : g->fwd;
-  o.rowptr = c.rowptr; o.colidx = c.colidx; o.row_order = c.row_order; o.hub_segptr = c.hub_segptr;
-  o.seg_row = c.seg_row; o.seg_begin = c.seg_begin; o.seg_end = c.seg_end;
-  o.dinv_gather = transpose ? g->dinv_dst : g->dinv_src;
+  o.colidx = c.colidx; o.head = c.head; o.wave_desc = c.wave_desc; o.hub_desc = c.hub_desc; o.seg_desc = c.seg_desc;
+  o.colscale = c.colscale; o.head_scale = c.head_scale;
   o.dinv_row = transpose ? g->dinv_src : g->dinv_dst;
-  o.dinv_out = o.dinv_gather;
+  o.dinv_out = transpose ? g->dinv_dst : g->dinv_src;
   o.x = in.x; o.slab = g->slab; o.e_out = in.e_out; o.acc_in = in.acc_in; o.acc_out = in.acc_out;
   o.n = g->n; o.n_hub = c.n_hub; o.n_wave = c.n_wave; o.n_group = c.n_group; o.n_seg = c.n_seg;
   o.flags = in.flags; o.slope = in.slope;
@@ -235,7 +258,7 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
 int launch_layer(const dg_layer_task *tasks, int32_t n_tasks, int transpose, hipStream_t stream) {
   dg_task_batch batch;
   batch.n_tasks = n_tasks;
-  int32_t blocks = 0, seg_blocks = 0;
+  int32_t blocks = 0, hub_blocks = 0;
   for (int k = 0; k < n_tasks; ++k) {
     int rc = fill_task(tasks[k], transpose, batch.t[k]);
     if (rc) return rc;
@@ -244,13 +267,13 @@ int launch_layer(const dg_layer_task *tasks, int32_t n_tasks, int transpose, hip
         return dg_fail(DG_ERR_ARG, "layer tasks %d and %d share a graph with hub rows (one slab per graph)", j, k);
     dg_task_dev &t = batch.t[k];
     t.blk_begin = blocks;
-    t.seg_blk_begin = seg_blocks;
-    blocks += ((t.n_hub + 3) >> 2) + ((t.n_wave + 3) >> 2) + ((t.n_group + 15) >> 4);
-    seg_blocks += (t.n_seg + 3) >> 2;
+    t.hub_blk_begin = hub_blocks;
+    blocks += ((t.n_seg + 3) >> 2) + ((t.n_wave + 3) >> 2) + ((t.n_group + 15) >> 4);
+    hub_blocks += (t.n_hub + 3) >> 2;
   }
   for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
-  if (seg_blocks > 0) hipLaunchKernelGGL(hub_partial_kernel, dim3(seg_blocks), dim3(256), 0, stream, batch);
   if (blocks > 0) hipLaunchKernelGGL(gcn_layer_kernel, dim3(blocks), dim3(256), 0, stream, batch);
+  if (hub_blocks > 0) hipLaunchKernelGGL(hub_reduce_kernel, dim3(hub_blocks), dim3(256), 0, stream, batch);
   DG_HIP(hipGetLastError());
   return 0;
 }

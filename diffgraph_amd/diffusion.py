@@ -164,6 +164,7 @@ class GaussianDiffusion(nn.Module):
     def training_losses2(self, model, targetEmbeds, x_start, batch, ts=None, noise=None):  # Model.py:348-366
         n = x_start.size(0)
         dev = x_start.device
+        validate = ts is not None  # caller-supplied timesteps are range-checked (one host sync)
         if ts is None:
             ts = torch.randint(0, self.steps, (n,), device=dev).long()
         if noise is None and self.noise_scale != 0:
@@ -178,7 +179,7 @@ class GaussianDiffusion(nn.Module):
         sa = self._dev("sqrt_alphas_cumprod", dev) if self.noise_scale != 0 else None
         sb = self._dev("sqrt_one_minus_alphas_cumprod", dev) if self.noise_scale != 0 else None
         row_loss, out, _ = ops.diffusion_loss_fwd(p, targetEmbeds.contiguous(), xs, noise, ts, sa, sb,
-                                                  self._dev("loss_weight", dev, torch.float64))
+                                                  self._dev("loss_weight", dev, torch.float64), validate=validate)
         return row_loss[batch], out
 
     def mean_flat(self, tensor):  # Model.py:368-369
