@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdiffgraph_hip.so")
 DG_D = 64
 DG_MAX_TASKS = 8
 DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE = 1, 2, 4
+DG_BWD_SAVED_PRESCALED = 8
 
 
 class DiffGraphHipError(RuntimeError):
@@ -25,6 +26,11 @@ class DiffGraphHipError(RuntimeError):
 class LayerTask(C.Structure):
     _fields_ = [("graph", C.c_void_p), ("x", C.c_void_p), ("e_out", C.c_void_p), ("acc_in", C.c_void_p),
                 ("acc_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float)]
+
+
+class BwdTask(C.Structure):
+    _fields_ = [("graph", C.c_void_p), ("w_in", C.c_void_p), ("e_saved", C.c_void_p), ("d_sum", C.c_void_p),
+                ("w_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float)]
 
 
 class Denoiser(C.Structure):
@@ -47,6 +53,7 @@ SIGNATURES = {
     "dg_spmm_norm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int,
                                        C.c_void_p]),
     "dg_gcn_layer_fwd": (C.c_int, [C.POINTER(LayerTask), C.c_int32, C.c_int32, C.c_void_p]),
+    "dg_gcn_layer_bwd": (C.c_int, [C.POINTER(BwdTask), C.c_int32, C.c_int32, C.c_void_p]),
     "dg_sum_tables": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dg_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                               C.c_int32, C.c_void_p, C.c_void_p]),
@@ -58,6 +65,8 @@ SIGNATURES = {
     "dg_diffusion_loss_fwd": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dg_diffusion_loss_bwd": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_int32] + [C.c_void_p] * 9 +
+                              [C.c_int64, C.c_int32] + [C.c_void_p] * 7),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -12,6 +12,8 @@
 #define DG_ERR_DIM (-2)
 #define DG_ERR_SIZE (-3)
 
+#define DG_EPI_BWD 0x100  // internal flag: backward epilogue
+
 // Records a printf-style message retrievable through dg_last_error(); returns `code`.
 int dg_fail(int code, const char *fmt, ...);
 
@@ -63,6 +65,8 @@ struct dg_task_dev {
   float *e_out;
   const float *acc_in;
   float *acc_out;
+  const float *e_saved;  // backward: saved forward activation of this layer (NULL: layer 0)
+  const float *d_sum;    // backward: gradient wrt the layer sum
   int32_t n, n_hub, n_wave, n_group, n_seg;
   int32_t flags;
   float slope;

@@ -44,6 +44,11 @@ struct dn_task {
   float *out;
   double *row_loss;
   float *x_t_out;
+  // backward of the loss (loss_bwd_kernel)
+  const double *g_row;                // dL/d row_loss [n]
+  const float *g_out;                 // dL/d out [n][64] or NULL
+  float *d_x_start, *d_target;        // [n][64]
+  float *dout_tot, *hid, *dpre, *xn;  // [n][64] each: operands of the weight-gradient GEMMs
   int64_t n;
   int32_t n_steps, norm, blk_begin;
 };
@@ -190,6 +195,128 @@ __global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch bat
   }
 }
 
+// Backward of training_losses2 for a 32-row tile per wavefront: recomputes the forward
+// (q_sample, normalise, two contractions, tanh), then runs the two transposed contractions.
+// Weight gradients are left to two [64 x n].[n x 64] library GEMMs over the stored
+// dout_tot / hid / dpre / xn tables.
+__global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch batch) {
+  // images 0,1: W_in[:, :64], W_out (as in denoise_kernel); 2: W_out^T; 3: W_in[:, :64]^T
+  __shared__ f32x4 wl[4 * 2 * 2 * 4 * 64];
+  const int b = blockIdx.x;
+  int ti_ = 0;
+  for (int k = 1; k < batch.n_tasks; ++k)
+    if (b >= batch.t[k].blk_begin) ti_ = k;
+  const dn_task &T = batch.t[ti_];
+  for (int idx = threadIdx.x; idx < 4 * 2 * 2 * 4 * 64; idx += blockDim.x) {
+    const int ln = idx & 63, rq = (idx >> 6) & 3, ti = (idx >> 8) & 1, to = (idx >> 9) & 1, m = idx >> 10;
+    const int row = 32 * to + (ln & 31), col = 32 * ti + 8 * rq + 4 * (ln >> 5);
+    f32x4 v;
+    if (m == 0) v = *reinterpret_cast<const f32x4 *>(T.w_in + row * 72 + col);
+    else if (m == 1) v = *reinterpret_cast<const f32x4 *>(T.w_out + row * 64 + col);
+    else {
+      const float *w = m == 2 ? T.w_out : T.w_in;
+      const int ld = m == 2 ? 64 : 72;
+      v = f32x4{w[(col + 0) * ld + row], w[(col + 1) * ld + row], w[(col + 2) * ld + row], w[(col + 3) * ld + row]};
+    }
+    wl[idx] = v;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int64_t row = ((int64_t)(b - T.blk_begin) * kWavesPerBlock + wave) * kRowsPerWave + j;
+  const bool valid = row < T.n;
+  const int64_t ro = row * DG_D;
+  int t = 0;
+  if (valid) t = min(max((int)T.t[row], 0), T.n_steps - 1);
+
+  f32x16 xs[2];
+  load_tile(T.x + ro, h, valid, xs);
+  float a_t = 1.0f;
+  if (T.sqrt_ac != nullptr) {
+    f32x16 nz[2];
+    load_tile(T.noise + ro, h, valid, nz);
+    a_t = T.sqrt_ac[t];
+    const float s_t = T.sqrt_1mac[t];
+    xs[0] = a_t * xs[0] + s_t * nz[0];
+    xs[1] = a_t * xs[1] + s_t * nz[1];
+  }
+  // forward recompute
+  float nrm = 1.0f;
+  f32x16 xn[2] = {xs[0], xs[1]};
+  if (T.norm) {
+    float ss = 0.f;
+#pragma unroll
+    for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ss += xs[tau][r] * xs[tau][r];
+    ss += __shfl_xor(ss, 32);
+    nrm = fmaxf(sqrtf(ss), 1e-12f);
+    const float inv = 1.0f / nrm;
+    xn[0] = xs[0] * inv;
+    xn[1] = xs[1] * inv;
+  }
+  store_tile(T.xn + ro, h, valid, xn);
+  f32x16 hid[2], out[2];
+  load_tile(T.time_bias + t * DG_D, h, true, hid);
+  contract64(wl, lane, xn, hid);
+#pragma unroll
+  for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[tau][r] = tanhf(hid[tau][r]);
+  store_tile(T.hid + ro, h, valid, hid);
+  load_tile(T.b_out, h, true, out);
+  contract64(wl + 1 * 1024, lane, hid, out);
+  // d out = g_out + g_row * w_t * 2 (out - target) / 64 ;  d target = -(second term)
+  {
+    f32x16 tg[2];
+    load_tile(T.target + ro, h, valid, tg);
+    float coef = 0.f;
+    if (valid) coef = (float)(T.g_row[row] * T.loss_w[t] * (2.0 / DG_D));
+    f32x16 dl[2] = {coef * (out[0] - tg[0]), coef * (out[1] - tg[1])};
+    f32x16 ng[2] = {-dl[0], -dl[1]};
+    store_tile(T.d_target + ro, h, valid, ng);
+    out[0] = dl[0];
+    out[1] = dl[1];
+    if (T.g_out != nullptr) {
+      load_tile(T.g_out + ro, h, valid, tg);
+      out[0] += tg[0];
+      out[1] += tg[1];
+    }
+  }
+  store_tile(T.dout_tot + ro, h, valid, out);
+  // dh = W_out^T dout ; dpre = (1 - h^2) dh
+  f32x16 dh[2];
+  dh[0] = dh[1] = f32x16{0.f};
+  contract64(wl + 2 * 1024, lane, out, dh);
+#pragma unroll
+  for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[tau][r] = (1.0f - hid[tau][r] * hid[tau][r]) * dh[tau][r];
+  store_tile(T.dpre + ro, h, valid, dh);
+  // dxn = W_in[:, :64]^T dpre ; through F.normalize and q_sample
+  f32x16 dx[2];
+  dx[0] = dx[1] = f32x16{0.f};
+  contract64(wl + 3 * 1024, lane, dh, dx);
+  if (T.norm) {
+    float ng = 0.f;
+#pragma unroll
+    for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ng += xn[tau][r] * dx[tau][r];
+    ng += __shfl_xor(ng, 32);
+    const float inv = 1.0f / nrm;
+    if (nrm > 1e-12f) {
+      dx[0] = (dx[0] - xn[0] * ng) * inv;
+      dx[1] = (dx[1] - xn[1] * ng) * inv;
+    } else {
+      dx[0] = dx[0] * inv;
+      dx[1] = dx[1] * inv;
+    }
+  }
+  dx[0] = dx[0] * a_t;
+  dx[1] = dx[1] * a_t;
+  store_tile(T.d_x_start + ro, h, valid, dx);
+}
+
 __global__ __launch_bounds__(256) void q_sample_kernel(const f32x4 *__restrict__ x0, const f32x4 *__restrict__ noise,
                                                        const int64_t *__restrict__ t, const float *__restrict__ sa,
                                                        const float *__restrict__ sb, f32x4 *__restrict__ xt, int64_t n4) {
@@ -320,4 +447,32 @@ extern "C" int dg_diffusion_loss_fwd(const dg_denoiser *dn, const float *time_bi
   k.loss_w = loss_w; k.out = out; k.row_loss = row_loss; k.x_t_out = x_t_out; k.n = n; k.n_steps = n_steps;
   k.norm = dn->norm;
   return launch_one<MODE_LOSS>(k, (hipStream_t)stream);
+}
+
+extern "C" int dg_diffusion_loss_bwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps, const float *target,
+                                     const float *x_start, const float *noise, const int64_t *ts, const float *sqrt_ac,
+                                     const float *sqrt_1mac, const double *loss_w, const double *g_row_loss,
+                                     const float *g_out, int64_t n, int32_t d, float *d_x_start, float *d_target,
+                                     float *dout_tot, float *hid, float *dpre, float *xn, void *stream) {
+  int rc = check_denoiser("dg_diffusion_loss_bwd", dn, time_bias, n_steps, d);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!target || !x_start || !ts || !loss_w || !g_row_loss || !d_x_start || !d_target || !dout_tot || !hid || !dpre ||
+      !xn || n < 0)
+    return dg_fail(DG_ERR_ARG, "dg_diffusion_loss_bwd: NULL argument");
+  if ((sqrt_ac != nullptr) != (sqrt_1mac != nullptr) || (sqrt_ac && !noise))
+    return dg_fail(DG_ERR_ARG, "dg_diffusion_loss_bwd: sqrt_ac, sqrt_1mac and noise go together");
+  dn_task k = {};
+  k.w_in = dn->w_in; k.w_out = dn->w_out; k.b_out = dn->b_out; k.time_bias = time_bias;
+  k.x = x_start; k.noise = noise; k.target = target; k.t = ts; k.sqrt_ac = sqrt_ac; k.sqrt_1mac = sqrt_1mac;
+  k.loss_w = loss_w; k.g_row = g_row_loss; k.g_out = g_out; k.d_x_start = d_x_start; k.d_target = d_target;
+  k.dout_tot = dout_tot; k.hid = hid; k.dpre = dpre; k.xn = xn; k.n = n; k.n_steps = n_steps; k.norm = dn->norm;
+  dn_batch batch;
+  k.blk_begin = 0;
+  for (int i = 0; i < kDnMaxTasks; ++i) batch.t[i] = k;
+  batch.n_tasks = 1;
+  const int64_t blocks = (n + kRowsPerBlock - 1) / kRowsPerBlock;
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, batch);
+  DG_HIP(hipGetLastError());
+  return 0;
 }

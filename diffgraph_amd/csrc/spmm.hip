@@ -114,20 +114,62 @@ __device__ __forceinline__ float sum16(float v) {
 // arrives while they load.
 struct row_ctx {
   float di, dout;
-  f32x4 a_in;
+  f32x4 a_in;  // forward: running layer sum; backward: saved activation
+  f32x4 g_in;  // backward: gradient wrt the layer sum
 };
 
 __device__ __forceinline__ row_ctx load_row_ctx(const dg_task_dev &T, int row, int l) {
   row_ctx c;
+  const size_t o = (size_t)row * (DG_D / 4) + l;
   c.di = T.dinv_row[row];
-  c.dout = (T.flags & DG_OUT_PRESCALE) ? T.dinv_out[row] : 1.0f;
   c.a_in = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (T.acc_out) c.a_in = reinterpret_cast<const f32x4 *>(T.acc_in)[(size_t)row * (DG_D / 4) + l];
+  c.g_in = c.a_in;
+  if (T.flags & DG_EPI_BWD) {
+    c.dout = T.dinv_out[row];
+    if (T.e_saved) {
+      c.a_in = reinterpret_cast<const f32x4 *>(T.e_saved)[o];
+      c.g_in = reinterpret_cast<const f32x4 *>(T.d_sum)[o];
+    }
+    return c;
+  }
+  c.dout = (T.flags & DG_OUT_PRESCALE) ? T.dinv_out[row] : 1.0f;
+  if (T.acc_out) c.a_in = reinterpret_cast<const f32x4 *>(T.acc_in)[o];
   return c;
+}
+
+// Backward of LeakyReLU + F.normalize + layer sum for one row (see dg_gcn_layer_bwd).
+__device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, const row_ctx &rc, f32x4 acc, int l) {
+  const size_t o = (size_t)row * (DG_D / 4) + l;
+  f32x4 G = acc * rc.di;
+  if (!T.e_saved) {
+    reinterpret_cast<f32x4 *>(T.e_out)[o] = G;
+    return;
+  }
+  const f32x4 e = rc.a_in, g = rc.g_in;
+  const float c = (T.flags & DG_BWD_SAVED_PRESCALED) ? rc.di : 1.0f;  // e = c * E_l
+  const float re = sqrtf(sum16(e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w));
+  const float r = re / c;                                              // ||E_l||
+  f32x4 dE;
+  if (r > 1e-12f) {  // y/||y||: d = (g - n (n.g)) / ||y||
+    const f32x4 n = e / re;
+    const float ng = sum16(n.x * g.x + n.y * g.y + n.z * g.z + n.w * g.w);
+    dE = (g - n * ng) / r;
+  } else {           // clamp_min(norm, eps) is active: y / eps
+    dE = g / 1e-12f;
+  }
+  dE += G;
+  const float slope = T.slope;
+  f32x4 dz;
+  dz.x = e.x > 0.f ? dE.x : dE.x * slope;
+  dz.y = e.y > 0.f ? dE.y : dE.y * slope;
+  dz.z = e.z > 0.f ? dE.z : dE.z * slope;
+  dz.w = e.w > 0.f ? dE.w : dE.w * slope;
+  reinterpret_cast<f32x4 *>(T.e_out)[o] = dz * rc.dout;
 }
 
 // rst*norm, LeakyReLU, F.normalize, layer sum, next layer's input (Model.py:165-172,67-70).
 __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const row_ctx &rc, f32x4 acc, int l) {
+  if (T.flags & DG_EPI_BWD) return epilogue_bwd(T, row, rc, acc, l);
   const float slope = T.slope;
   f32x4 y = acc * rc.di;
   y.x = y.x > 0.f ? y.x : y.x * slope;
@@ -223,8 +265,18 @@ __global__ __launch_bounds__(256) void hub_reduce_kernel(const dg_task_batch bat
   if (q == 0) epilogue(T, d.x, rc, acc, l);
 }
 
+// Rows with nothing to gather (last layer of the backward pass): epilogue only, 16 lanes per row.
+__global__ __launch_bounds__(256) void rowwise_kernel(const dg_task_batch batch) {
+  const dg_task_dev &T = find_task(batch, blockIdx.x, false);
+  const int l = threadIdx.x & 15;
+  const int row = (blockIdx.x - T.blk_begin) * 16 + (threadIdx.x >> 4);
+  if (row >= T.n) return;
+  const row_ctx rc = load_row_ctx(T, row, l);
+  epilogue(T, row, rc, f32x4{0.f, 0.f, 0.f, 0.f}, l);
+}
+
 struct sum_args {
-  const float *in[8];
+  const float *in[16];
   int32_t n_in;
 };
 
@@ -252,18 +304,16 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   o.x = in.x; o.slab = g->slab; o.e_out = in.e_out; o.acc_in = in.acc_in; o.acc_out = in.acc_out;
   o.n = g->n; o.n_hub = c.n_hub; o.n_wave = c.n_wave; o.n_group = c.n_group; o.n_seg = c.n_seg;
   o.flags = in.flags; o.slope = in.slope;
+  o.e_saved = nullptr; o.d_sum = nullptr;
   return 0;
 }
 
-int launch_layer(const dg_layer_task *tasks, int32_t n_tasks, int transpose, hipStream_t stream) {
-  dg_task_batch batch;
-  batch.n_tasks = n_tasks;
+int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_t stream) {
+  const int n_tasks = batch.n_tasks;
   int32_t blocks = 0, hub_blocks = 0;
   for (int k = 0; k < n_tasks; ++k) {
-    int rc = fill_task(tasks[k], transpose, batch.t[k]);
-    if (rc) return rc;
     for (int j = 0; j < k; ++j)
-      if (tasks[j].graph == tasks[k].graph && batch.t[k].n_seg > 0)
+      if (graphs[j] == graphs[k] && batch.t[k].n_seg > 0)
         return dg_fail(DG_ERR_ARG, "layer tasks %d and %d share a graph with hub rows (one slab per graph)", j, k);
     dg_task_dev &t = batch.t[k];
     t.blk_begin = blocks;
@@ -276,6 +326,18 @@ int launch_layer(const dg_layer_task *tasks, int32_t n_tasks, int transpose, hip
   if (hub_blocks > 0) hipLaunchKernelGGL(hub_reduce_kernel, dim3(hub_blocks), dim3(256), 0, stream, batch);
   DG_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_layer(const dg_layer_task *tasks, int32_t n_tasks, int transpose, hipStream_t stream) {
+  dg_task_batch batch;
+  const dg_graph *graphs[DG_MAX_TASKS];
+  batch.n_tasks = n_tasks;
+  for (int k = 0; k < n_tasks; ++k) {
+    int rc = fill_task(tasks[k], transpose, batch.t[k]);
+    if (rc) return rc;
+    graphs[k] = tasks[k].graph;
+  }
+  return launch_batch(batch, graphs, stream);
 }
 
 }  // namespace
@@ -296,12 +358,53 @@ extern "C" int dg_spmm_norm_act_fwd(dg_graph *g, const float *x, float *y, int32
   return launch_layer(&t, 1, transpose, (hipStream_t)stream);
 }
 
+extern "C" int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32_t d, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_gcn_layer_bwd: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!tasks || n_tasks <= 0 || n_tasks > DG_MAX_TASKS)
+    return dg_fail(DG_ERR_ARG, "dg_gcn_layer_bwd: n_tasks must be in [1,%d] (got %d)", DG_MAX_TASKS, n_tasks);
+  // tasks with a gather (w_in) go through the transposed propagation launch; the others are row-wise
+  dg_task_batch gather, rowwise;
+  const dg_graph *ggraphs[DG_MAX_TASKS];
+  gather.n_tasks = rowwise.n_tasks = 0;
+  int32_t row_blocks = 0;
+  for (int k = 0; k < n_tasks; ++k) {
+    const dg_bwd_task &b = tasks[k];
+    if (!b.graph || !b.w_out) return dg_fail(DG_ERR_ARG, "backward task %d: NULL graph or output", k);
+    if (!b.w_in && !b.e_saved) return dg_fail(DG_ERR_ARG, "backward task %d: neither w_in nor e_saved given", k);
+    if (b.e_saved && !b.d_sum) return dg_fail(DG_ERR_ARG, "backward task %d: e_saved needs d_sum", k);
+    if (b.w_out == b.w_in) return dg_fail(DG_ERR_ARG, "backward task %d: w_out must not alias w_in", k);
+    dg_layer_task lt;
+    lt.graph = b.graph; lt.x = b.w_in ? b.w_in : b.w_out; lt.e_out = b.w_out; lt.acc_in = nullptr; lt.acc_out = nullptr;
+    lt.flags = DG_IN_PRESCALED | DG_EPI_BWD | (b.flags & DG_BWD_SAVED_PRESCALED); lt.slope = b.slope;
+    dg_task_batch &dst = b.w_in ? gather : rowwise;
+    dg_task_dev &t = dst.t[dst.n_tasks];
+    lt.x = b.w_in ? b.w_in : b.d_sum;  // fill_task only checks x for NULL / aliasing
+    int rc = fill_task(lt, 1, t);
+    if (rc) return rc;
+    t.e_saved = b.e_saved; t.d_sum = b.d_sum;
+    if (b.w_in) {
+      ggraphs[dst.n_tasks] = b.graph;
+    } else {
+      t.blk_begin = row_blocks;
+      row_blocks += (t.n + 15) >> 4;
+    }
+    dst.n_tasks++;
+  }
+  if (rowwise.n_tasks > 0) {
+    for (int k = rowwise.n_tasks; k < DG_MAX_TASKS; ++k) rowwise.t[k] = rowwise.t[0];
+    hipLaunchKernelGGL(rowwise_kernel, dim3(row_blocks), dim3(256), 0, (hipStream_t)stream, rowwise);
+    DG_HIP(hipGetLastError());
+  }
+  if (gather.n_tasks > 0) return launch_batch(gather, ggraphs, (hipStream_t)stream);
+  return 0;
+}
+
 extern "C" int dg_sum_tables(const float *const *in, int32_t n_in, float *out, int64_t n_elems, void *stream) {
-  if (!in || !out || n_in < 1 || n_in > 8) return dg_fail(DG_ERR_ARG, "dg_sum_tables: n_in must be in [1,8]");
+  if (!in || !out || n_in < 1 || n_in > 16) return dg_fail(DG_ERR_ARG, "dg_sum_tables: n_in must be in [1,16]");
   if (n_elems % 4 != 0) return dg_fail(DG_ERR_ARG, "dg_sum_tables: element count must be a multiple of 4");
   sum_args a;
   a.n_in = n_in;
-  for (int k = 0; k < 8; ++k) a.in[k] = in[k < n_in ? k : 0];
+  for (int k = 0; k < 16; ++k) a.in[k] = in[k < n_in ? k : 0];
   const int64_t n4 = n_elems / 4;
   if (n4 == 0) return 0;
   int64_t blocks = (n4 + 255) / 256;

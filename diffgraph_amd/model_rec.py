@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
+from ._lib import DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
 from .diffusion import Denoise, GaussianDiffusion
 from .layers import DGLLayer
 
@@ -31,6 +31,46 @@ DEFAULT_ARGS = SimpleNamespace(latdim=64, gcn_layer=2, dims="[64]", d_emb_size=8
 
 def pairPredict(ancEmbeds, posEmbeds, negEmbeds):  # DiffGraph-Rec/Utils/Utils.py:4-8
     return (ancEmbeds * posEmbeds).sum(-1) - (ancEmbeds * negEmbeds).sum(-1)
+
+
+class _PropagateFn(torch.autograd.Function):
+    """HGDM.propagate as one differentiable op.  The forward keeps, per graph, every layer's
+    activation (scaled by the source norm, as the next layer consumed it; the last layer's
+    unscaled); the backward walks the layers down with the transposed propagation kernel."""
+
+    @staticmethod
+    def forward(ctx, e0, model):
+        e0 = e0.contiguous()
+        ui, het, saved = model._propagate(e0, keep=True)
+        ctx.model, ctx.saved = model, saved
+        return ui, het
+
+    @staticmethod
+    def backward(ctx, d_ui, d_het):
+        model, saved = ctx.model, ctx.saved
+        graphs = [model.target_adj] + model.behavior_mats
+        slope, L = float(model.act.negative_slope), model.n_layers
+        ref = saved[0][0]
+        d_ui = torch.zeros_like(ref) if d_ui is None else d_ui.contiguous()
+        d_het = torch.zeros_like(ref) if d_het is None else d_het.contiguous()
+        d_sum = [d_ui] + [d_het] * (len(graphs) - 1)
+        w = [None] * len(graphs)
+        for l in range(L, 0, -1):
+            tasks = []
+            for g, graph in enumerate(graphs):
+                out = torch.empty_like(ref)
+                tasks.append(ops.BwdTask(graph, w[g], saved[g][l - 1], d_sum[g], out,
+                                         DG_BWD_SAVED_PRESCALED if l < L else 0, slope))
+                w[g] = out
+            ops.gcn_layer_bwd_batched(tasks)
+        tasks = []
+        for g, graph in enumerate(graphs):
+            out = torch.empty_like(ref)
+            tasks.append(ops.BwdTask(graph, w[g], None, None, out, 0, slope))
+            w[g] = out
+        ops.gcn_layer_bwd_batched(tasks)
+        # every graph's layer sum starts from e0 (Model.py:57,74): d e0 = sum_g (d_sum_g + G0_g)
+        return ops.sum_tables(d_sum + w), None
 
 
 class HGDM(nn.Module):
@@ -70,31 +110,38 @@ class HGDM(nn.Module):
 
     def propagate(self, e0: torch.Tensor):
         """Returns (ui_embeddings [N,64], all_heter_embeddings [N,64])  (Model.py:61-87)."""
+        if torch.is_grad_enabled() and e0.requires_grad:
+            return _PropagateFn.apply(e0, self)
+        ui, het, _ = self._propagate(e0.detach().contiguous(), keep=False)
+        return ui, het
+
+    def _propagate(self, e0: torch.Tensor, keep: bool):
         graphs = [self.target_adj] + self.behavior_mats
         slope = float(self.act.negative_slope)
         L = self.n_layers
         sums = [torch.empty_like(e0) for _ in graphs]
         prev: List[Optional[torch.Tensor]] = [None] * len(graphs)
+        saved = [[] for _ in graphs]
         for l in range(L):
             last = l == L - 1
             tasks = []
             for g, graph in enumerate(graphs):
-                e_out = None if last else torch.empty_like(e0)
+                e_out = None if (last and not keep) else torch.empty_like(e0)
                 flags = (DG_IN_PRESCALED if l > 0 else 0) | (0 if last else DG_OUT_PRESCALE)
                 tasks.append(ops.LayerTask(graph, e0 if l == 0 else prev[g], e_out, e0 if l == 0 else sums[g], sums[g],
                                            flags, slope))
                 prev[g] = e_out
+                saved[g].append(e_out)
             hook = getattr(self, "layer_hook", None)
             if hook is not None:
                 hook("begin", l)
             ops.gcn_layer_batched(tasks)
             if hook is not None:
                 hook("end", l)
-        return sums[0], ops.sum_tables(sums[1:])
+        return sums[0], ops.sum_tables(sums[1:]), saved
 
     def forward(self):
-        e0 = self.embedding_table.detach()
-        ui, het = self.propagate(e0)
+        ui, het = self.propagate(self.embedding_table)
         nu = self.n_user
         return ui[:nu], ui[nu:], het[:nu], het[nu:]
 
@@ -110,7 +157,10 @@ class HGDM(nn.Module):
         ancEmbeds, posEmbeds, negEmbeds = usrEmbeds[ancs], itmEmbeds[poss], itmEmbeds[negs]
         scoreDiff = pairPredict(ancEmbeds, posEmbeds, negEmbeds)
         bprLoss = -(scoreDiff).sigmoid().log().sum() / args.batch
-        regLoss = ((torch.norm(ancEmbeds) ** 2 + torch.norm(posEmbeds) ** 2 + torch.norm(negEmbeds) ** 2) * args.reg) / args.batch
+        # ||x||_2^2 written as sum(x^2): same value as the reference's torch.norm(x) ** 2 (Model.py:109) to
+        # rounding, and safe under HIP-graph replay (torch's full-tensor norm reduction is not, on this build)
+        sq = lambda x: x.square().sum()
+        regLoss = ((sq(ancEmbeds) + sq(posEmbeds) + sq(negEmbeds)) * args.reg) / args.batch
         loss = bprLoss + regLoss + diff_loss
         return loss, bprLoss, regLoss, diff_loss
 

@@ -90,6 +90,38 @@ def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
     _lib.check(rc, "dg_gcn_layer_fwd")
 
 
+@dataclass
+class BwdTask:
+    graph: CSRGraph
+    w_in: Optional[torch.Tensor]      # scaled dZ of the layer above, or None for the last layer
+    e_saved: Optional[torch.Tensor]   # this layer's forward activation, or None for layer 0
+    d_sum: Optional[torch.Tensor]     # gradient wrt the graph's layer sum
+    w_out: torch.Tensor
+    flags: int = 0
+    slope: float = 0.5
+
+
+def gcn_layer_bwd_batched(tasks: Sequence[BwdTask]) -> None:
+    """Backward of one fused propagation layer over several graphs (see dg_gcn_layer_bwd)."""
+    if not tasks:
+        return
+    n_tasks = len(tasks)
+    if n_tasks > _lib.DG_MAX_TASKS:
+        raise DiffGraphHipError(f"at most {_lib.DG_MAX_TASKS} graphs per batched layer launch")
+    arr = (_lib.BwdTask * n_tasks)()
+    for k, t in enumerate(tasks):
+        n = t.graph.num_nodes()
+        _table(t.w_out, "w_out", n)
+        for nm in ("w_in", "e_saved", "d_sum"):
+            v = getattr(t, nm)
+            if v is not None:
+                _table(v, nm, n)
+        arr[k] = _lib.BwdTask(t.graph.handle, _ptr(t.w_in), _ptr(t.e_saved), _ptr(t.d_sum), t.w_out.data_ptr(),
+                              int(t.flags), float(t.slope))
+    rc = _lib.load().dg_gcn_layer_bwd(arr, n_tasks, DG_D, _lib.stream_ptr(tasks[0].w_out.device))
+    _lib.check(rc, "dg_gcn_layer_bwd")
+
+
 def sum_tables(tables: Sequence[torch.Tensor]) -> torch.Tensor:
     """((t0 + t1) + t2) + ... like Python's sum(list) (Model.py:87)."""
     if len(tables) == 1:
@@ -206,3 +238,39 @@ def diffusion_loss_fwd(dn: DenoiserParams, target: torch.Tensor, x_start: torch.
                                            row_loss.data_ptr(), _ptr(x_t), _lib.stream_ptr(x_start.device))
     _lib.check(rc, "dg_diffusion_loss_fwd")
     return row_loss, out, x_t
+
+
+GEMM_SPLIT = 64
+
+
+def splitk_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T @ b for tall [n_pad,64] tables as GEMM_SPLIT independent slices summed afterwards (a single
+    [64 x n].[n x 64] GEMM leaves the library one tile of work per CU or less)."""
+    s = GEMM_SPLIT
+    return torch.bmm(a.view(s, -1, a.shape[1]).transpose(1, 2), b.view(s, -1, b.shape[1])).sum(0)
+
+
+def diffusion_loss_bwd(dn: DenoiserParams, target, x_start, noise, ts, sqrt_ac, sqrt_1mac, loss_w, g_row_loss, g_out):
+    """Backward of diffusion_loss_fwd.  Returns (d_x_start, d_target, dout_tot, hid, dpre, xn)."""
+    n = x_start.shape[0]
+    n_steps = loss_w.numel()
+    _table(x_start, "x_start")
+    _table(target, "targetEmbeds", n)
+    _vec(g_row_loss, "grad of row_loss", torch.float64, n)
+    if g_out is not None:
+        _table(g_out, "grad of out", n)
+    tb = dn.time_bias(n_steps)
+    outs = [torch.empty_like(x_start) for _ in range(2)]
+    # the four GEMM operand tables are padded with zero rows to a multiple of GEMM_SPLIT rows so the
+    # caller can run the [64 x n].[n x 64] reductions as a batched (split-K) GEMM
+    n_pad = -(-n // GEMM_SPLIT) * GEMM_SPLIT
+    for _ in range(4):
+        t = torch.empty((n_pad, DG_D), dtype=torch.float32, device=x_start.device)
+        t[n:].zero_()
+        outs.append(t)
+    rc = _lib.load().dg_diffusion_loss_bwd(C.byref(dn.c), tb.data_ptr(), n_steps, target.data_ptr(), x_start.data_ptr(),
+                                           _ptr(noise) if sqrt_ac is not None else None, ts.data_ptr(), _ptr(sqrt_ac),
+                                           _ptr(sqrt_1mac), loss_w.data_ptr(), g_row_loss.data_ptr(), _ptr(g_out), n, DG_D,
+                                           *[o.data_ptr() for o in outs], _lib.stream_ptr(x_start.device))
+    _lib.check(rc, "dg_diffusion_loss_bwd")
+    return tuple(outs)

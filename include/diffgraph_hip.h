@@ -99,8 +99,34 @@ typedef struct dg_layer_task {
 
 int dg_gcn_layer_fwd(const dg_layer_task *tasks, int32_t n_tasks, int32_t d, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * a11: backward of one fused propagation layer, batched over graphs.  Replaces what
+ * autograd records for DGLLayer.forward + F.normalize + the layer sum
+ * (loss.backward(), DiffGraph-Rec/main.py:127) -- DGL's SpMM backward is the SpMM over
+ * reversed edges.  With node j, layer l, saved activation E_l and d_sum = dLoss/d(layer sum):
+ *     G[j]     = dinv_src[j] * sum_{j->i} w_in[i]                (0 when w_in == NULL)
+ *     dE[j]    = G[j] + normalize_backward(d_sum[j]; E_l[j])
+ *     w_out[j] = dinv_dst[j] * LeakyReLU'(E_l[j]) * dE[j]        (dZ_l, scaled for the next gather)
+ * and, when e_saved == NULL (layer 0, the embedding table itself):  w_out[j] = G[j].
+ * DG_BWD_SAVED_PRESCALED says e_saved holds dinv_src[j]*E_l[j] (what a forward call with
+ * DG_OUT_PRESCALE wrote); otherwise it holds E_l[j].
+ * ---------------------------------------------------------------------------------- */
+enum { DG_BWD_SAVED_PRESCALED = 8 };
+
+typedef struct dg_bwd_task {
+  dg_graph *graph;
+  const float *w_in;     /* dZ_{l+1} scaled by dinv_dst, [n][64], or NULL for the last layer */
+  const float *e_saved;  /* activation of layer l from the forward pass, or NULL for layer 0 */
+  const float *d_sum;    /* gradient wrt this graph's layer sum, [n][64] (unused when e_saved == NULL) */
+  float *w_out;
+  int32_t flags;
+  float slope;
+} dg_bwd_task;
+
+int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32_t d, void *stream);
+
 /* out[i] = ((in[0][i] + in[1][i]) + in[2][i]) ... left to right; replaces Python
- * sum(list) over per-behaviour sums (DiffGraph-Rec/Model.py:87).  n_in <= 8. */
+ * sum(list) over per-behaviour sums (DiffGraph-Rec/Model.py:87).  n_in <= 16. */
 int dg_sum_tables(const float *const *in_host, int32_t n_in, float *out, int64_t n_elems,
                   void *stream);
 
@@ -156,6 +182,20 @@ int dg_diffusion_loss_fwd(const dg_denoiser *dn, const float *time_bias, int32_t
                           const int64_t *ts, const float *sqrt_ac, const float *sqrt_1mac,
                           const double *loss_w, int64_t n, int32_t d, float *out, double *row_loss,
                           float *x_t_out, void *stream);
+
+/* a11: backward of dg_diffusion_loss_fwd (what autograd records for training_losses2,
+ * DiffGraph-Rec/Model.py:348-366).  g_row_loss: DEVICE fp64[n] = dL/d row_loss; g_out: DEVICE
+ * [n][64] = dL/d out from downstream users of `out`, or NULL.  Writes dL/d x_start and
+ * dL/d target, and the four [n][64] tables whose products give the weight gradients:
+ *     dW_out = dout_tot^T . hid      db_out = colsum(dout_tot)
+ *     dW_in[:, :64] = dpre^T . xn    d time_bias[t] = sum_{i: ts_i = t} dpre[i]
+ * (two plain GEMMs and a 200-row scatter the caller runs with its BLAS). */
+int dg_diffusion_loss_bwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps,
+                          const float *target, const float *x_start, const float *noise,
+                          const int64_t *ts, const float *sqrt_ac, const float *sqrt_1mac,
+                          const double *loss_w, const double *g_row_loss, const float *g_out,
+                          int64_t n, int32_t d, float *d_x_start, float *d_target, float *dout_tot,
+                          float *hid, float *dpre, float *xn, void *stream);
 
 #ifdef __cplusplus
 }

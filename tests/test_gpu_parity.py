@@ -147,7 +147,7 @@ def test_rec_forward_retail_rocket_shape_golden():
     outs = m.forward()
     for o, nm, rows in zip(outs, ("tu", "ti", "hu", "hi"), ("rows_u", "rows_i", "rows_u", "rows_i")):
         assert_rows_close(o[T(fx[rows]).to(DEV)], fx[f"fwd_{nm}_rows"], what=nm)
-        np.testing.assert_allclose(o.double().sum(0).cpu().numpy(), fx[f"fwd_{nm}_colsum"], rtol=0,
+        np.testing.assert_allclose(o.detach().double().sum(0).cpu().numpy(), fx[f"fwd_{nm}_colsum"], rtol=0,
                                    atol=1e-5 * fx[f"fwd_{nm}_abssum"].max())
     pu, pi = m.predict()
     assert_rows_close(pu[T(fx["rows_u"]).to(DEV)], fx["predict_u_rows"], what="predict user rows")
@@ -238,7 +238,7 @@ def test_training_losses2_golden():
                                     ts=dev(fx["tl_ts"]), noise=dev(fx["tl_noise"]))
     assert loss.dtype == torch.float64
     assert_rows_close(out, fx["tl_out"], what="training_losses2 out")
-    np.testing.assert_allclose(loss.cpu().numpy(), fx["tl_loss"], rtol=1e-5)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), fx["tl_loss"], rtol=1e-5)
 
 
 def test_rec_cal_loss_values_golden():
@@ -250,7 +250,7 @@ def test_rec_cal_loss_values_golden():
     m.args = SimpleNamespace(**{**vars(m.args), "batch": int(fx["cl_batch_div"][0]), "reg": float(fx["cl_batch_div"][1])})
     vals = m.cal_loss(dev(fx["cl_ancs"]), dev(fx["cl_poss"]), dev(fx["cl_negs"]), dev(fx["cl_ts_u"]), dev(fx["cl_noise_u"]),
                       dev(fx["cl_ts_i"]), dev(fx["cl_noise_i"]))
-    np.testing.assert_allclose([float(v) for v in vals], fx["cl_losses"], rtol=1e-5)
+    np.testing.assert_allclose([float(v.detach()) for v in vals], fx["cl_losses"], rtol=1e-5)
 
 
 # ------------------------------------------------------------------------------ a3 (DBLP)
@@ -285,7 +285,7 @@ def test_nc_dblp_golden(tag):
         onehot = torch.zeros(NA, 4)
         onehot[torch.arange(NA), T(load("dblp_graph.npz")["labels"])] = 1.0
         nll, diff = model.cal_loss(dev(fx["cl_ancs"]), dev(onehot), adjs, dev(features), dev(fx["cl_ts"]), dev(fx["cl_noise"]))
-        np.testing.assert_allclose([float(nll), float(diff)], fx["cl_losses"], rtol=2e-5)
+        np.testing.assert_allclose([float(nll.detach()), float(diff.detach())], fx["cl_losses"], rtol=2e-5)
 
 
 # ------------------------------------------------------------------------------ full size
@@ -312,3 +312,51 @@ def test_tmall_size_properties():
     a = (u64 * ops.spmm_norm_act(g, z, 1.0).double()).sum()
     b = (y.double() * v64).sum()
     assert abs(float(a - b)) <= 1e-6 * max(abs(float(a)), float((u64.abs() * v64.abs()).sum()) * 1e-3)
+
+
+# ------------------------------------------------------------------------------ a11 (backward)
+def test_propagation_backward_matches_oracle_autograd():
+    """d/d e0 of <ui, R1> + <het, R2> through the fused propagation, against torch autograd on the oracle."""
+    fx, nu, ni, target, behs = tiny_fixture()
+    wl = dgdata.rec_workload("tiny")
+    for kw in ({}, {"group_max": 2, "seg_len": 64}):
+        graphs = [graph_of(*ui, nu, ni, **kw) for ui in [wl.target] + wl.behaviours]
+        from types import SimpleNamespace
+        m = dg.rec.HGDM(SimpleNamespace(userNum=nu, itemNum=ni, target_adj=graphs[0], behavior_mats=graphs[1:])).eval()
+        m.set_embeddings(dev(fx["user_emb"]), dev(fx["item_emb"]))
+        gen = torch.Generator().manual_seed(4)
+        r1, r2 = torch.randn(nu + ni, 64, generator=gen), torch.randn(nu + ni, 64, generator=gen)
+        ui, het = m.propagate(m.embedding_table)
+        ((ui * dev(r1)).sum() + (het * dev(r2)).sum()).backward()
+        ue = T(fx["user_emb"]).clone().requires_grad_(True)
+        ie = T(fx["item_emb"]).clone().requires_grad_(True)
+        tu, ti, hu, hi = O.rec_forward(target, behs, ue, ie, 2)
+        ((torch.cat([tu, ti]) * r1).sum() + (torch.cat([hu, hi]) * r2).sum()).backward()
+        want = torch.cat([ue.grad, ie.grad])
+        # isolated nodes get d/dx of x/eps = 1e12 * g from F.normalize; compare those rows relatively too
+        assert_rows_close(m.embedding_table.grad, want, rtol=2e-5, what=f"d e0 {kw}")
+
+
+def test_rec_cal_loss_gradients_golden():
+    """loss.backward() through the HIP path reproduces the REFERENCE's gradients (captured from its
+    own cal_loss().backward()) for the embeddings and all denoiser weights."""
+    fx, nu, ni, *_ = tiny_fixture()
+    wl = dgdata.rec_workload("tiny")
+    m = rec_model(wl, fx)
+    m.set_embeddings(dev(fx["user_emb"]), dev(fx["item_emb"]))
+    from types import SimpleNamespace
+    m.args = SimpleNamespace(**{**vars(m.args), "batch": int(fx["cl_batch_div"][0]), "reg": float(fx["cl_batch_div"][1])})
+    loss, bpr, reg, diff = m.cal_loss(dev(fx["cl_ancs"]), dev(fx["cl_poss"]), dev(fx["cl_negs"]), dev(fx["cl_ts_u"]),
+                                      dev(fx["cl_noise_u"]), dev(fx["cl_ts_i"]), dev(fx["cl_noise_i"]))
+    np.testing.assert_allclose([float(loss), float(bpr), float(reg), float(diff)], fx["cl_losses"], rtol=1e-5)
+    loss.backward()
+    g = m.embedding_table.grad
+    assert_rows_close(g[:nu], fx["cl_grad_user"], rtol=1e-4, what="grad user_emb")
+    assert_rows_close(g[nu:], fx["cl_grad_item"], rtol=1e-4, what="grad item_emb")
+    for pre, dn in (("usr_", m.usr_denoiser), ("item_", m.item_denoiser)):
+        got = {"w_emb": dn.emb_layer.weight.grad, "b_emb": dn.emb_layer.bias.grad, "w_in": dn.in_layers[0].weight.grad,
+               "b_in": dn.in_layers[0].bias.grad, "w_out": dn.out_layers[0].weight.grad, "b_out": dn.out_layers[0].bias.grad}
+        for nm, gv in got.items():
+            want = fx["cl_grad_" + pre + nm]
+            scale = np.abs(want).max()
+            np.testing.assert_allclose(gv.cpu().numpy(), want, rtol=0, atol=1e-4 * scale, err_msg="grad " + pre + nm)
