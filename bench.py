@@ -108,9 +108,10 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+    if world > 1 or args.workload == "industry":
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=device)
         from diffgraph_amd import dist as dgdist
         return dgdist.bench_sharded(args, rank, world, device)
 

@@ -25,7 +25,8 @@ class DiffGraphHipError(RuntimeError):
 
 class LayerTask(C.Structure):
     _fields_ = [("graph", C.c_void_p), ("x", C.c_void_p), ("e_out", C.c_void_p), ("acc_in", C.c_void_p),
-                ("acc_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float)]
+                ("acc_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float), ("partial_out", C.c_void_p),
+                ("partial_from", C.c_int32)]
 
 
 class BwdTask(C.Structure):
@@ -45,6 +46,8 @@ SIGNATURES = {
     "dg_last_error": (C.c_char_p, []),
     "dg_graph_create": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_void_p)]),
+    "dg_graph_create_ex": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_int32, C.POINTER(C.c_void_p)]),
     "dg_graph_destroy": (None, [C.c_void_p]),
     "dg_graph_num_nodes": (C.c_int32, [C.c_void_p]),
     "dg_graph_num_edges": (C.c_int64, [C.c_void_p]),
@@ -53,6 +56,8 @@ SIGNATURES = {
     "dg_spmm_norm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int,
                                        C.c_void_p]),
     "dg_gcn_layer_fwd": (C.c_int, [C.POINTER(LayerTask), C.c_int32, C.c_int32, C.c_void_p]),
+    "dg_gcn_partial_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "dg_gcn_layer_bwd": (C.c_int, [C.POINTER(BwdTask), C.c_int32, C.c_int32, C.c_void_p]),
     "dg_sum_tables": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dg_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,

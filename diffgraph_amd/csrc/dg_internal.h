@@ -65,6 +65,8 @@ struct dg_task_dev {
   float *e_out;
   const float *acc_in;
   float *acc_out;
+  float *partial_out;    // sharded: raw neighbour sums of rows >= partial_from (NULL: off)
+  int32_t partial_from;
   const float *e_saved;  // backward: saved forward activation of this layer (NULL: layer 0)
   const float *d_sum;    // backward: gradient wrt the layer sum
   int32_t n, n_hub, n_wave, n_group, n_seg;

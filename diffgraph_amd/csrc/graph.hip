@@ -148,6 +148,12 @@ void free_csr(dg_csr &d) {
 
 extern "C" int dg_graph_create(int32_t n, int64_t nnz, const int32_t *src, const int32_t *dst,
                                int32_t group_max, int32_t seg_len, dg_graph **out) {
+  return dg_graph_create_ex(n, nnz, src, dst, nullptr, nullptr, group_max, seg_len, out);
+}
+
+extern "C" int dg_graph_create_ex(int32_t n, int64_t nnz, const int32_t *src, const int32_t *dst,
+                                  const int32_t *out_deg_host, const int32_t *in_deg_host, int32_t group_max,
+                                  int32_t seg_len, dg_graph **out) {
   if (!out) return dg_fail(DG_ERR_ARG, "dg_graph_create: out is NULL");
   *out = nullptr;
   if (n <= 0) return dg_fail(DG_ERR_ARG, "dg_graph_create: n_nodes must be positive (got %d)", n);
@@ -175,8 +181,8 @@ extern "C" int dg_graph_create(int32_t n, int64_t nnz, const int32_t *src, const
   // with correctly rounded sqrt and divide, which is what this does.
   std::vector<float> dsrc(n), ddst(n);
   for (int32_t i = 0; i < n; ++i) {
-    int32_t in_deg = f.rowptr[i + 1] - f.rowptr[i];
-    int32_t out_deg = b.rowptr[i + 1] - b.rowptr[i];
+    int32_t in_deg = in_deg_host ? in_deg_host[i] : f.rowptr[i + 1] - f.rowptr[i];
+    int32_t out_deg = out_deg_host ? out_deg_host[i] : b.rowptr[i + 1] - b.rowptr[i];
     ddst[i] = 1.0f / sqrtf((float)std::max(in_deg, 1));
     dsrc[i] = 1.0f / sqrtf((float)std::max(out_deg, 1));
   }

@@ -170,6 +170,10 @@ __device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, cons
 // rst*norm, LeakyReLU, F.normalize, layer sum, next layer's input (Model.py:165-172,67-70).
 __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const row_ctx &rc, f32x4 acc, int l) {
   if (T.flags & DG_EPI_BWD) return epilogue_bwd(T, row, rc, acc, l);
+  if (T.partial_out != nullptr && row >= T.partial_from) {  // another rank holds the rest of this row
+    reinterpret_cast<f32x4 *>(T.partial_out)[(size_t)(row - T.partial_from) * (DG_D / 4) + l] = acc;
+    return;
+  }
   const float slope = T.slope;
   f32x4 y = acc * rc.di;
   y.x = y.x > 0.f ? y.x : y.x * slope;
@@ -265,6 +269,21 @@ __global__ __launch_bounds__(256) void hub_reduce_kernel(const dg_task_batch bat
   if (q == 0) epilogue(T, d.x, rc, acc, l);
 }
 
+// Row-sharded layer, second half: sum the ranks' partial neighbour sums of a row in rank
+// order, then the usual epilogue.  16 lanes per row.
+__global__ __launch_bounds__(256) void partial_finalize_kernel(const dg_task_dev T, const float *__restrict__ partials,
+                                                               int n_parts, int row_begin, int n_rows) {
+  const int l = threadIdx.x & 15;
+  const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (r >= n_rows) return;
+  const int row = row_begin + r;
+  const row_ctx rc = load_row_ctx(T, row, l);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < n_parts; ++p)
+    acc += reinterpret_cast<const f32x4 *>(partials)[((size_t)p * n_rows + r) * (DG_D / 4) + l];
+  epilogue(T, row, rc, acc, l);
+}
+
 // Rows with nothing to gather (last layer of the backward pass): epilogue only, 16 lanes per row.
 __global__ __launch_bounds__(256) void rowwise_kernel(const dg_task_batch batch) {
   const dg_task_dev &T = find_task(batch, blockIdx.x, false);
@@ -305,6 +324,7 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   o.n = g->n; o.n_hub = c.n_hub; o.n_wave = c.n_wave; o.n_group = c.n_group; o.n_seg = c.n_seg;
   o.flags = in.flags; o.slope = in.slope;
   o.e_saved = nullptr; o.d_sum = nullptr;
+  o.partial_out = in.partial_out; o.partial_from = in.partial_from;
   return 0;
 }
 
@@ -355,7 +375,29 @@ extern "C" int dg_spmm_norm_act_fwd(dg_graph *g, const float *x, float *y, int32
   if (!g || !x || !y) return dg_fail(DG_ERR_ARG, "dg_spmm_norm_act_fwd: NULL argument");
   dg_layer_task t;
   t.graph = g; t.x = x; t.e_out = y; t.acc_in = nullptr; t.acc_out = nullptr; t.flags = 0; t.slope = slope;
+  t.partial_out = nullptr; t.partial_from = 0;
   return launch_layer(&t, 1, transpose, (hipStream_t)stream);
+}
+
+extern "C" int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_parts, int32_t row_begin,
+                                       int32_t n_rows, float *e_out, const float *acc_in, float *acc_out, int32_t flags,
+                                       float slope, int32_t d, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_gcn_partial_finalize: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!graph || !partials || n_parts <= 0) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: NULL argument");
+  if (row_begin < 0 || n_rows < 0 || (int64_t)row_begin + n_rows > graph->n)
+    return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: rows [%d,%d) outside the graph's %d nodes", row_begin,
+                   row_begin + n_rows, graph->n);
+  if (n_rows == 0) return 0;
+  dg_layer_task lt;
+  lt.graph = graph; lt.x = partials; lt.e_out = e_out; lt.acc_in = acc_in; lt.acc_out = acc_out;
+  lt.flags = flags; lt.slope = slope; lt.partial_out = nullptr; lt.partial_from = 0;
+  dg_task_dev t;
+  int rc = fill_task(lt, 0, t);
+  if (rc) return rc;
+  hipLaunchKernelGGL(partial_finalize_kernel, dim3((n_rows + 15) >> 4), dim3(256), 0, (hipStream_t)stream, t, partials,
+                     n_parts, row_begin, n_rows);
+  DG_HIP(hipGetLastError());
+  return 0;
 }
 
 extern "C" int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32_t d, void *stream) {
@@ -376,6 +418,7 @@ extern "C" int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32
     dg_layer_task lt;
     lt.graph = b.graph; lt.x = b.w_in ? b.w_in : b.w_out; lt.e_out = b.w_out; lt.acc_in = nullptr; lt.acc_out = nullptr;
     lt.flags = DG_IN_PRESCALED | DG_EPI_BWD | (b.flags & DG_BWD_SAVED_PRESCALED); lt.slope = b.slope;
+    lt.partial_out = nullptr; lt.partial_from = 0;
     dg_task_batch &dst = b.w_in ? gather : rowwise;
     dg_task_dev &t = dst.t[dst.n_tasks];
     lt.x = b.w_in ? b.w_in : b.d_sum;  // fill_task only checks x for NULL / aliasing

@@ -16,16 +16,28 @@ from . import _lib
 
 
 class CSRGraph:
-    def __init__(self, src, dst, num_nodes: int, group_max: int = 0, seg_len: int = 0):
+    def __init__(self, src, dst, num_nodes: int, group_max: int = 0, seg_len: int = 0, out_degrees=None,
+                 in_degrees=None):
+        """out_degrees / in_degrees (int32[num_nodes]) override the degrees counted from the given
+        edges; a rank holding an edge shard passes the whole graph's degrees."""
         src = np.ascontiguousarray(np.asarray(src), dtype=np.int32)
         dst = np.ascontiguousarray(np.asarray(dst), dtype=np.int32)
         if src.shape != dst.shape or src.ndim != 1:
             raise ValueError("src and dst must be 1-D arrays of equal length")
+        degs = []
+        for d in (out_degrees, in_degrees):
+            if d is not None:
+                d = np.ascontiguousarray(np.asarray(d), dtype=np.int32)
+                if d.shape != (int(num_nodes),):
+                    raise ValueError("degree overrides must have one entry per node")
+            degs.append(d)
         lib = _lib.load()
         h = C.c_void_p()
-        rc = lib.dg_graph_create(int(num_nodes), int(src.size), src.ctypes.data, dst.ctypes.data,
-                                 int(group_max), int(seg_len), C.byref(h))
-        _lib.check(rc, "dg_graph_create")
+        rc = lib.dg_graph_create_ex(int(num_nodes), int(src.size), src.ctypes.data, dst.ctypes.data,
+                                    None if degs[0] is None else degs[0].ctypes.data,
+                                    None if degs[1] is None else degs[1].ctypes.data,
+                                    int(group_max), int(seg_len), C.byref(h))
+        _lib.check(rc, "dg_graph_create_ex")
         self._h = h
         self._n = int(num_nodes)
         self._nnz = int(src.size)

@@ -66,6 +66,8 @@ class LayerTask:
     acc_out: Optional[torch.Tensor] = None
     flags: int = 0
     slope: float = 0.5
+    partial_out: Optional[torch.Tensor] = None   # sharded runs: raw neighbour sums of rows >= partial_from
+    partial_from: int = 0
 
 
 def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
@@ -84,10 +86,28 @@ def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
             v = getattr(t, nm)
             if v is not None:
                 _table(v, nm, n)
+        if t.partial_out is not None:
+            _table(t.partial_out, "partial_out", n - int(t.partial_from))
         arr[k] = _lib.LayerTask(t.graph.handle, t.x.data_ptr(), _ptr(t.e_out), _ptr(t.acc_in), _ptr(t.acc_out),
-                                int(t.flags), float(t.slope))
+                                int(t.flags), float(t.slope), _ptr(t.partial_out), int(t.partial_from))
     rc = _lib.load().dg_gcn_layer_fwd(arr, n_tasks, DG_D, _lib.stream_ptr(dev))
     _lib.check(rc, "dg_gcn_layer_fwd")
+
+
+def gcn_partial_finalize(graph: CSRGraph, partials: torch.Tensor, row_begin: int, e_out, acc_in, acc_out, flags: int,
+                         slope: float) -> None:
+    """partials: [n_parts, n_rows, 64] partial neighbour sums of rows [row_begin, row_begin+n_rows)."""
+    if partials.dim() != 3 or partials.shape[2] != DG_D or partials.dtype != torch.float32 or not partials.is_cuda \
+            or not partials.is_contiguous():
+        raise DiffGraphHipError("partials: expected a contiguous float32 GPU tensor [n_parts, n_rows, 64]")
+    n = graph.num_nodes()
+    for nm, v in (("e_out", e_out), ("acc_in", acc_in), ("acc_out", acc_out)):
+        if v is not None:
+            _table(v, nm, n)
+    rc = _lib.load().dg_gcn_partial_finalize(graph.handle, partials.data_ptr(), partials.shape[0], int(row_begin),
+                                             partials.shape[1], _ptr(e_out), _ptr(acc_in), _ptr(acc_out), int(flags),
+                                             float(slope), DG_D, _lib.stream_ptr(partials.device))
+    _lib.check(rc, "dg_gcn_partial_finalize")
 
 
 @dataclass

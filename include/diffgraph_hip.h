@@ -54,6 +54,13 @@ typedef struct dg_graph dg_graph;
 int dg_graph_create(int32_t n_nodes, int64_t n_edges, const int32_t *src_host,
                     const int32_t *dst_host, int32_t group_max, int32_t seg_len,
                     dg_graph **out);
+/* Same, with the node degrees supplied by the caller (int32[n_nodes], NULL = count the given
+ * edges).  A rank that holds only a shard of the edges passes the GLOBAL degrees so that its
+ * norms equal the whole graph's. */
+int dg_graph_create_ex(int32_t n_nodes, int64_t n_edges, const int32_t *src_host,
+                       const int32_t *dst_host, const int32_t *out_deg_host,
+                       const int32_t *in_deg_host, int32_t group_max, int32_t seg_len,
+                       dg_graph **out);
 void dg_graph_destroy(dg_graph *g);
 int32_t dg_graph_num_nodes(const dg_graph *g);
 int64_t dg_graph_num_edges(const dg_graph *g);
@@ -95,9 +102,23 @@ typedef struct dg_layer_task {
   float *acc_out;        /* running layer sum out (may alias acc_in), or NULL */
   int32_t flags;
   float slope;
+  /* Row-sharded runs: rows with id >= partial_from only hold part of their neighbour list on
+   * this rank; their plain neighbour sum (no norm, no activation) goes to
+   * partial_out[row - partial_from][64] and nothing else is written for them.
+   * partial_out == NULL disables this. */
+  float *partial_out;
+  int32_t partial_from;
 } dg_layer_task;
 
 int dg_gcn_layer_fwd(const dg_layer_task *tasks, int32_t n_tasks, int32_t d, void *stream);
+
+/* Second half of a row-sharded layer: for rows [row_begin, row_begin + n_rows) of `graph`,
+ * add the n_parts partial neighbour sums  partials[p][r][64]  (p = 0..n_parts-1 in order,
+ * gathered from the ranks) and apply the epilogue of dg_gcn_layer_fwd (norm of the receiving
+ * node, LeakyReLU, normalise, layer sum, next layer's input) with the same flags. */
+int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_parts,
+                            int32_t row_begin, int32_t n_rows, float *e_out, const float *acc_in,
+                            float *acc_out, int32_t flags, float slope, int32_t d, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * a11: backward of one fused propagation layer, batched over graphs.  Replaces what

@@ -1,0 +1,53 @@
+"""A torch-CPU stand-in for diffgraph_amd.dist.HipBackend, used ONLY by the gloo tests of the
+sharding orchestration.  It implements the documented semantics of dg_gcn_layer_fwd (with
+partial_out / partial_from) and dg_gcn_partial_finalize with the oracle's arithmetic."""
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from diffgraph_amd._lib import DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE
+
+
+class CpuBackend:
+    def make_graph(self, lg, n_nodes):
+        deg = torch.from_numpy(lg.degrees).float().clamp(min=1)
+        return SimpleNamespace(src=torch.from_numpy(lg.src).long(), dst=torch.from_numpy(lg.dst).long(), n=n_nodes,
+                               dinv=torch.pow(deg, -0.5).view(-1, 1))
+
+    def empty(self, rows):
+        return torch.full((rows, 64), float("nan"))
+
+    @staticmethod
+    def _epilogue(g, rows, s, e_out, acc_in, acc_out, flags, slope):
+        y = F.leaky_relu(s * g.dinv[rows], slope)
+        yn = F.normalize(y, p=2, dim=1)
+        if acc_out is not None:
+            acc_out[rows] = acc_in[rows] + yn
+        if e_out is not None:
+            e = yn if flags & DG_OUT_NORM else y
+            e_out[rows] = e * g.dinv[rows] if flags & DG_OUT_PRESCALE else e
+
+    def layer(self, tasks):
+        for t in tasks:
+            g, x = t["graph"], t["x"]
+            h = x if t["flags"] & DG_IN_PRESCALED else x * g.dinv
+            s = torch.zeros_like(h).index_add_(0, g.dst, h[g.src])
+            pf = t["partial_from"] if t["partial_out"] is not None else g.n
+            if t["partial_out"] is not None:
+                t["partial_out"].copy_(s[pf:])
+            rows = slice(0, pf)
+            self._epilogue(g, rows, s[rows], t["e_out"], t["acc_in"], t["acc_out"], t["flags"], t["slope"])
+
+    def finalize(self, g, partials, row_begin, e_out, acc_in, acc_out, flags, slope):
+        s = torch.zeros_like(partials[0])
+        for p in range(partials.shape[0]):
+            s = s + partials[p]
+        rows = slice(row_begin, row_begin + partials.shape[1])
+        self._epilogue(g, rows, s, e_out, acc_in, acc_out, flags, slope)
+
+    def sum_tables(self, tables):
+        out = tables[0]
+        for t in tables[1:]:
+            out = out + t
+        return out

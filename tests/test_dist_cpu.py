@@ -1,0 +1,87 @@
+"""The row-sharded propagation (diffgraph_amd.dist) with world_size 2 over gloo on CPU: partition,
+global degree norms, the one exchange per layer and the fixed summation order, against the
+single-process oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffgraph_amd import data as dgdata
+from diffgraph_amd.dist import ShardedRecPropagation, shard_bipartite, user_ranges
+from oracle import ref_cpu as O
+from tests.cpu_backend import CpuBackend
+from tests.helpers import assert_rows_close, edges_t
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _workload():
+    n_user, n_item = 301, 23
+    inter = [dgdata.synth_interactions(n_user, n_item, m, seed) for m, seed in ((900, 1), (2500, 2), (400, 3))]
+    ue = torch.from_numpy(dgdata.xavier_uniform(n_user, 64, seed=5))
+    ie = torch.from_numpy(dgdata.xavier_uniform(n_item, 64, seed=6))
+    return n_user, n_item, inter, ue, ie
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    n_user, n_item, inter, ue, ie = _workload()
+    prop = ShardedRecPropagation(inter, n_user, n_item, rank, world, CpuBackend())
+    e0 = torch.cat([ue[prop.u0:prop.u1], ie])
+    ui, het = prop.forward(e0)
+    q.put((rank, prop.u0, prop.u1, ui.numpy(), het.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partition_covers_users_and_keeps_global_degrees():
+    assert user_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    n_user, n_item, inter, *_ = _workload()
+    u, i = inter[1]
+    total = 0
+    for (u0, u1) in user_ranges(n_user, 4):
+        lg = shard_bipartite(u, i, n_user, n_item, u0, u1)
+        total += len(lg.src)
+        np.testing.assert_array_equal(lg.degrees[: u1 - u0], np.bincount(u, minlength=n_user)[u0:u1])
+        np.testing.assert_array_equal(lg.degrees[u1 - u0:], np.bincount(i, minlength=n_item))
+        assert lg.src.max() < (u1 - u0) + n_item and lg.n_edges_global == 2 * len(u)
+    assert total == 2 * len(u)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_forward_matches_oracle(world):
+    n_user, n_item, inter, ue, ie = _workload()
+    tu, ti, hu, hi = O.rec_forward(edges_t(*inter[0], n_user), [edges_t(*b, n_user) for b in inter[1:]], ue, ie, 2)
+    if world == 1:
+        prop = ShardedRecPropagation(inter, n_user, n_item, 0, 1, CpuBackend())
+        ui, het = prop.forward(torch.cat([ue, ie]))
+        results = [(0, 0, n_user, ui.numpy(), het.numpy())]
+    else:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = sorted(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    ui_users = np.concatenate([r[3][: r[2] - r[1]] for r in results])
+    het_users = np.concatenate([r[4][: r[2] - r[1]] for r in results])
+    assert_rows_close(ui_users, tu, what="target users")
+    assert_rows_close(het_users, hu, what="heter users")
+    for r in results:  # item rows: replicated, identical on every rank
+        assert_rows_close(r[3][r[2] - r[1]:], ti, what="target items")
+        assert_rows_close(r[4][r[2] - r[1]:], hi, what="heter items")
+        np.testing.assert_array_equal(r[3][r[2] - r[1]:], results[0][3][results[0][2] - results[0][1]:])

@@ -360,3 +360,71 @@ def test_rec_cal_loss_gradients_golden():
             want = fx["cl_grad_" + pre + nm]
             scale = np.abs(want).max()
             np.testing.assert_allclose(gv.cpu().numpy(), want, rtol=0, atol=1e-4 * scale, err_msg="grad " + pre + nm)
+
+
+# ------------------------------------------------------------------------------ (e) sharded
+def _run_sharded_threads(inter, n_user, n_item, e_user, e_item, world):
+    """`world` user shards on ONE GPU, one thread per emulated rank, lock-step fake all-gather."""
+    import threading
+    from diffgraph_amd.dist import HipBackend, ShardedRecPropagation
+    barrier = threading.Barrier(world)
+    shared = [None] * world
+    results = [None] * world
+    errors = []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            prop = ShardedRecPropagation(inter, n_user, n_item, rank, world, HipBackend(torch.device(DEV)))
+
+            def exchange(partials):
+                shared[rank] = partials
+                barrier.wait()
+                out = torch.stack(list(shared), dim=1).contiguous()
+                torch.cuda.synchronize()
+                barrier.wait()
+                return out
+            prop._exchange = exchange
+            e0 = torch.cat([e_user[prop.u0:prop.u1], e_item]).to(DEV)
+            ui, het = prop.forward(e0)
+            torch.cuda.synchronize()
+            results[rank] = (prop.u0, prop.u1, ui.cpu(), het.cpu())
+        except Exception as exc:  # surface failures instead of dead-locking the barrier
+            errors.append(exc)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_sharded_propagation_matches_single_gpu(world):
+    wl = dgdata.rec_workload("retail_rocket")
+    inter = [wl.target] + wl.behaviours
+    ue = T(dgdata.xavier_uniform(wl.n_user, 64, seed=0))
+    ie = T(dgdata.xavier_uniform(wl.n_item, 64, seed=1))
+    fx = load("rec_retail_rocket.npz")
+    m = rec_model(wl, fx)
+    m.set_embeddings(dev(ue), dev(ie))
+    with torch.no_grad():
+        ui_ref, het_ref = m.propagate(m.embedding_table)
+    res = _run_sharded_threads(inter, wl.n_user, wl.n_item, ue, ie, world)
+    nu = wl.n_user
+    ui_users = torch.cat([r[2][: r[1] - r[0]] for r in res])
+    het_users = torch.cat([r[3][: r[1] - r[0]] for r in res])
+    if world == 1:  # same kernels, same order: bit-identical to the unsharded path
+        assert torch.equal(ui_users, ui_ref[:nu].cpu()) and torch.equal(het_users, het_ref[:nu].cpu())
+    # with more ranks the item rows' partial sums are regrouped by rank (and layer-2 user rows read them)
+    assert_rows_close(ui_users, ui_ref[:nu], rtol=1e-6, what="sharded target users")
+    assert_rows_close(het_users, het_ref[:nu], rtol=1e-6, what="sharded heter users")
+    for r in res:  # item rows: partial sums regrouped by rank -> within 1e-6, identical on all ranks
+        assert_rows_close(r[2][r[1] - r[0]:], ui_ref[nu:], rtol=1e-6, what="sharded target items")
+        assert_rows_close(r[3][r[1] - r[0]:], het_ref[nu:], rtol=1e-6, what="sharded heter items")
+        assert torch.equal(r[2][r[1] - r[0]:], res[0][2][res[0][1] - res[0][0]:])
+    # and against the reference's golden rows
+    assert_rows_close(ui_users[T(fx["rows_u"])], fx["fwd_tu_rows"], what="sharded vs golden")
