@@ -40,6 +40,11 @@ class Denoiser(C.Structure):
                 ("norm", C.c_int32)]
 
 
+class PSampleTask(C.Structure):
+    _fields_ = [("dn", C.POINTER(Denoiser)), ("time_bias", C.c_void_p), ("x_T", C.c_void_p), ("x_0", C.c_void_p),
+                ("n", C.c_int64)]
+
+
 # name -> (restype, argtypes); one entry per symbol declared in include/diffgraph_hip.h
 SIGNATURES = {
     "dg_version": (C.c_int, []),
@@ -67,6 +72,8 @@ SIGNATURES = {
                                  C.c_int32, C.c_void_p, C.c_void_p]),
     "dg_p_sample_loop": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dg_p_sample_loop_batched": (C.c_int, [C.POINTER(PSampleTask), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_void_p]),
     "dg_diffusion_loss_fwd": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

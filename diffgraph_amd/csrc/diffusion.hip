@@ -430,6 +430,34 @@ extern "C" int dg_p_sample_loop(const dg_denoiser *dn, const float *time_bias, c
   return launch_one<MODE_PSAMPLE>(k, (hipStream_t)stream);
 }
 
+extern "C" int dg_p_sample_loop_batched(const dg_psample_task *tasks, int32_t n_tasks, const float *coef1,
+                                        const float *coef2, int32_t n_steps, int32_t d, void *stream) {
+  if (!tasks || n_tasks <= 0 || n_tasks > kDnMaxTasks)
+    return dg_fail(DG_ERR_ARG, "dg_p_sample_loop_batched: n_tasks must be in [1,%d]", kDnMaxTasks);
+  if (!coef1 || !coef2) return dg_fail(DG_ERR_ARG, "dg_p_sample_loop_batched: NULL coefficient table");
+  dn_batch batch;
+  batch.n_tasks = 0;
+  int64_t blocks = 0;
+  for (int k = 0; k < n_tasks; ++k) {
+    const dg_psample_task &t = tasks[k];
+    int rc = check_denoiser("dg_p_sample_loop_batched", t.dn, t.time_bias, n_steps, d);
+    if (rc) return rc;
+    if (t.n < 0 || (t.n > 0 && (!t.x_T || !t.x_0))) return dg_fail(DG_ERR_ARG, "dg_p_sample_loop_batched: task %d: bad table", k);
+    if (t.n == 0) continue;
+    dn_task q = {};
+    q.w_in = t.dn->w_in; q.w_out = t.dn->w_out; q.b_out = t.dn->b_out; q.time_bias = t.time_bias;
+    q.x = t.x_T; q.coef1 = coef1; q.coef2 = coef2; q.out = t.x_0; q.n = t.n; q.n_steps = n_steps; q.norm = t.dn->norm;
+    q.blk_begin = (int32_t)blocks;
+    blocks += (t.n + kRowsPerBlock - 1) / kRowsPerBlock;
+    batch.t[batch.n_tasks++] = q;
+  }
+  if (batch.n_tasks == 0) return 0;
+  for (int k = batch.n_tasks; k < kDnMaxTasks; ++k) batch.t[k] = batch.t[0];
+  hipLaunchKernelGGL(denoise_kernel<MODE_PSAMPLE>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, batch);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int dg_diffusion_loss_fwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps, const float *target,
                                      const float *x_start, const float *noise, const int64_t *ts, const float *sqrt_ac,
                                      const float *sqrt_1mac, const double *loss_w, int64_t n, int32_t d, float *out,

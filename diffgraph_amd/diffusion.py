@@ -222,6 +222,23 @@ class GaussianDiffusion(nn.Module):
         return ops.p_sample_loop(p, x_t.contiguous(), self._dev("posterior_mean_coef1", dev),
                                  self._dev("posterior_mean_coef2", dev))
 
+    def p_sample_many(self, pairs, steps, noises=None):
+        """p_sample for several (model, x_start) pairs in one fused launch (HGDM.predict runs the user and
+        the item denoiser back to back, Model.py:114-115)."""
+        prepared = []
+        for k, (model, x_start) in enumerate(pairs):
+            if steps == 0:
+                x_t = x_start
+            else:
+                t = torch.full((x_start.shape[0],), steps - 1, dtype=torch.long, device=x_start.device)
+                x_t = self.q_sample(x_start, t, None if noises is None else noises[k])
+            p = model.params(bool(model.norm))
+            p.time_bias(self.steps, refresh=True)
+            prepared.append((p, x_t.contiguous()))
+        dev = pairs[0][1].device
+        return ops.p_sample_loop_batched(prepared, self._dev("posterior_mean_coef1", dev),
+                                         self._dev("posterior_mean_coef2", dev))
+
     def training_losses2(self, model, targetEmbeds, x_start, batch, ts=None, noise=None):  # Model.py:348-366
         n = x_start.size(0)
         dev = x_start.device

@@ -167,6 +167,6 @@ class HGDM(nn.Module):
     def predict(self):  # Model.py:112-118
         usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = self.forward()
         dp = self.diffusion_process
-        denoised_u = dp.p_sample(self.usr_denoiser, h_usrEmbeds, self.args.sampling_steps)
-        denoised_i = dp.p_sample(self.item_denoiser, h_itemEmbeds, self.args.sampling_steps)
+        denoised_u, denoised_i = dp.p_sample_many([(self.usr_denoiser, h_usrEmbeds), (self.item_denoiser, h_itemEmbeds)],
+                                                  self.args.sampling_steps)
         return usrEmbeds + denoised_u, itmEmbeds + denoised_i

@@ -234,6 +234,26 @@ def p_sample_loop(dn: DenoiserParams, x_T: torch.Tensor, coef1: torch.Tensor, co
     return out
 
 
+def p_sample_loop_batched(pairs, coef1: torch.Tensor, coef2: torch.Tensor) -> List[torch.Tensor]:
+    """pairs: [(DenoiserParams, x_T), ...] -> [x_0, ...]; all reverse loops in one launch."""
+    n_steps = coef1.numel()
+    _vec(coef1, "posterior_mean_coef1", torch.float32)
+    _vec(coef2, "posterior_mean_coef2", torch.float32, n_steps)
+    arr = (_lib.PSampleTask * len(pairs))()
+    outs, keep = [], []
+    for k, (dn, x_T) in enumerate(pairs):
+        _table(x_T, "x_T")
+        tb = dn.time_bias(n_steps)
+        out = torch.empty_like(x_T)
+        outs.append(out)
+        keep.append(tb)
+        arr[k] = _lib.PSampleTask(C.pointer(dn.c), tb.data_ptr(), x_T.data_ptr(), out.data_ptr(), x_T.shape[0])
+    rc = _lib.load().dg_p_sample_loop_batched(arr, len(pairs), coef1.data_ptr(), coef2.data_ptr(), n_steps, DG_D,
+                                              _lib.stream_ptr(coef1.device))
+    _lib.check(rc, "dg_p_sample_loop_batched")
+    return outs
+
+
 def diffusion_loss_fwd(dn: DenoiserParams, target: torch.Tensor, x_start: torch.Tensor, noise: Optional[torch.Tensor],
                        ts: torch.Tensor, sqrt_ac: Optional[torch.Tensor], sqrt_1mac: Optional[torch.Tensor],
                        loss_w: torch.Tensor, want_x_t: bool = False, validate: bool = True):

@@ -192,6 +192,20 @@ int dg_p_sample_loop(const dg_denoiser *dn, const float *time_bias, const float 
                      const float *coef2, int32_t n_steps, const float *x_T, int64_t n, int32_t d,
                      float *x_0, void *stream);
 
+/* The same loop for several (denoiser, table) pairs in ONE launch -- e.g. the user and the item
+ * denoiser of HGDM.predict (DiffGraph-Rec/Model.py:114-115) -- so that a small table does not
+ * leave most of the chip idle.  n_tasks <= 4. */
+typedef struct dg_psample_task {
+  const dg_denoiser *dn;
+  const float *time_bias;
+  const float *x_T;
+  float *x_0;
+  int64_t n;
+} dg_psample_task;
+
+int dg_p_sample_loop_batched(const dg_psample_task *tasks, int32_t n_tasks, const float *coef1,
+                             const float *coef2, int32_t n_steps, int32_t d, void *stream);
+
 /* a9: GaussianDiffusion.training_losses2 forward (DiffGraph-Rec/Model.py:348-366) with the
  * random draws supplied by the caller: x_t = q_sample(x_start, ts, noise) (skipped when
  * sqrt_ac == NULL, the noise_scale == 0 case), out = Denoise(x_t, ts),
