@@ -106,12 +106,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)  # (> 1 rank per GPU only happens in single-GPU rehearsals over gloo)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1 or args.workload == "industry":
         if world > 1:
             import torch.distributed as dist
-            dist.init_process_group("nccl", device_id=device)
+            backend = os.environ.get("DG_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
         from diffgraph_amd import dist as dgdist
         return dgdist.bench_sharded(args, rank, world, device)
 

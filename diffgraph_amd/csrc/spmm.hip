@@ -132,8 +132,16 @@ __device__ __forceinline__ row_ctx load_row_ctx(const dg_task_dev &T, int row, i
     }
     return c;
   }
-  c.dout = (T.flags & DG_OUT_PRESCALE) ? T.dinv_out[row] : 1.0f;
+  const float dsrc = (T.flags & (DG_OUT_PRESCALE | DG_ACC_REBUILD)) ? T.dinv_out[row] : 1.0f;
+  c.dout = (T.flags & DG_OUT_PRESCALE) ? dsrc : 1.0f;
   if (T.acc_out) c.a_in = reinterpret_cast<const f32x4 *>(T.acc_in)[o];
+  if (T.flags & DG_ACC_REBUILD) {  // a_in = e0[i] + normalize(E_1[i]) from the stored dinv_src[i] * E_1[i]
+    const f32x4 p = reinterpret_cast<const f32x4 *>(T.x)[o];
+    const float np_ = sqrtf(sum16(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w));
+    // ||E_1|| = np_ / dsrc; F.normalize divides by max(||E_1||, 1e-12)
+    const float inv = (np_ > 1e-12f * dsrc) ? 1.0f / np_ : 1.0f / (1e-12f * dsrc);
+    c.a_in += p * inv;
+  }
   return c;
 }
 
@@ -151,11 +159,12 @@ __device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, cons
   const float r = re / c;                                              // ||E_l||
   f32x4 dE;
   if (r > 1e-12f) {  // y/||y||: d = (g - n (n.g)) / ||y||
-    const f32x4 n = e / re;
+    const float inv_re = 1.0f / re, inv_r = 1.0f / r;
+    const f32x4 n = e * inv_re;
     const float ng = sum16(n.x * g.x + n.y * g.y + n.z * g.z + n.w * g.w);
-    dE = (g - n * ng) / r;
+    dE = (g - n * ng) * inv_r;
   } else {           // clamp_min(norm, eps) is active: y / eps
-    dE = g / 1e-12f;
+    dE = g * 1e12f;
   }
   dE += G;
   const float slope = T.slope;
@@ -185,8 +194,9 @@ __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const ro
   f32x4 yn = y;
   if (want_norm) {
     float ss = sum16(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
-    const float den = fmaxf(sqrtf(ss), 1e-12f);
-    yn = y / den;
+    // one correctly rounded reciprocal per row, then multiplies: within 1 ulp of F.normalize's division
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    yn = y * inv;
   }
   if (T.acc_out) reinterpret_cast<f32x4 *>(T.acc_out)[o] = rc.a_in + yn;
   if (T.e_out) {
@@ -315,6 +325,8 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
     return dg_fail(DG_ERR_ARG, "layer task: acc_in and acc_out must both be set or both be NULL");
   if (!in.e_out && !in.acc_out) return dg_fail(DG_ERR_ARG, "layer task: no output requested");
   if (in.e_out == in.x) return dg_fail(DG_ERR_ARG, "layer task: e_out must not alias x");
+  if ((in.flags & DG_ACC_REBUILD) && (!(in.flags & DG_IN_PRESCALED) || !in.acc_out))
+    return dg_fail(DG_ERR_ARG, "layer task: DG_ACC_REBUILD needs DG_IN_PRESCALED and acc_in/acc_out");
   const dg_csr &c = transpose ? g->bwd : g->fwd;
   o.colidx = c.colidx; o.head = c.head; o.wave_desc = c.wave_desc; o.hub_desc = c.hub_desc; o.seg_desc = c.seg_desc;
   o.colscale = c.colscale; o.head_scale = c.head_scale;
@@ -380,16 +392,17 @@ extern "C" int dg_spmm_norm_act_fwd(dg_graph *g, const float *x, float *y, int32
 }
 
 extern "C" int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_parts, int32_t row_begin,
-                                       int32_t n_rows, float *e_out, const float *acc_in, float *acc_out, int32_t flags,
-                                       float slope, int32_t d, void *stream) {
+                                       int32_t n_rows, const float *x_prev, float *e_out, const float *acc_in,
+                                       float *acc_out, int32_t flags, float slope, int32_t d, void *stream) {
   if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_gcn_partial_finalize: embedding width %d unsupported (built for %d)", d, DG_D);
   if (!graph || !partials || n_parts <= 0) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: NULL argument");
   if (row_begin < 0 || n_rows < 0 || (int64_t)row_begin + n_rows > graph->n)
     return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: rows [%d,%d) outside the graph's %d nodes", row_begin,
                    row_begin + n_rows, graph->n);
   if (n_rows == 0) return 0;
+  if ((flags & DG_ACC_REBUILD) && !x_prev) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: DG_ACC_REBUILD needs x_prev");
   dg_layer_task lt;
-  lt.graph = graph; lt.x = partials; lt.e_out = e_out; lt.acc_in = acc_in; lt.acc_out = acc_out;
+  lt.graph = graph; lt.x = x_prev ? x_prev : partials; lt.e_out = e_out; lt.acc_in = acc_in; lt.acc_out = acc_out;
   lt.flags = flags; lt.slope = slope; lt.partial_out = nullptr; lt.partial_from = 0;
   dg_task_dev t;
   int rc = fill_task(lt, 0, t);

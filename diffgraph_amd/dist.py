@@ -27,7 +27,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ._lib import DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
+from ._lib import DG_ACC_REBUILD, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
 
 
 def user_ranges(n_user: int, world: int) -> List[Tuple[int, int]]:
@@ -78,9 +78,9 @@ class HipBackend:
         from . import ops
         ops.gcn_layer_batched([ops.LayerTask(**t) for t in tasks])
 
-    def finalize(self, graph, partials, row_begin, e_out, acc_in, acc_out, flags, slope) -> None:
+    def finalize(self, graph, partials, row_begin, e_out, acc_in, acc_out, flags, slope, x=None) -> None:
         from . import ops
-        ops.gcn_partial_finalize(graph, partials, row_begin, e_out, acc_in, acc_out, flags, slope)
+        ops.gcn_partial_finalize(graph, partials, row_begin, e_out, acc_in, acc_out, flags, slope, x=x)
 
     def sum_tables(self, tables):
         from . import ops
@@ -107,6 +107,12 @@ class ShardedRecPropagation:
         if self.world == 1:
             return partials.unsqueeze(1)
         import torch.distributed as dist
+        if partials.is_cuda and dist.get_backend(self.group) == "gloo":
+            # single-GPU rehearsal of the multi-process path: gloo moves host memory
+            host = partials.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(parts, host, group=self.group)
+            return torch.stack(parts, dim=1).contiguous().to(partials.device)
         parts = [torch.empty_like(partials) for _ in range(self.world)]
         dist.all_gather(parts, partials, group=self.group)
         return torch.stack(parts, dim=1).contiguous()
@@ -120,21 +126,25 @@ class ShardedRecPropagation:
         for l in range(L):
             last = l == L - 1
             flags = (DG_IN_PRESCALED if l > 0 else 0) | (0 if last else DG_OUT_PRESCALE)
+            skip_sum = l == 0 and L >= 2          # the second layer rebuilds e0 + normalize(E_1) itself
+            if l == 1:
+                flags |= DG_ACC_REBUILD
             partials = torch.empty((G, self.n_item, DG_D), dtype=torch.float32, device=e0.device)
             outs, tasks = [], []
             for g in range(G):
                 e_out = None if last else be.empty(self.n)
                 outs.append(e_out)
+                acc_in = None if skip_sum else (e0 if l <= 1 else sums[g])
                 tasks.append(dict(graph=self.graphs[g], x=e0 if l == 0 else prev[g], e_out=e_out,
-                                  acc_in=e0 if l == 0 else sums[g], acc_out=sums[g], flags=flags, slope=self.slope,
+                                  acc_in=acc_in, acc_out=None if skip_sum else sums[g], flags=flags, slope=self.slope,
                                   partial_out=partials[g], partial_from=self.n_loc))
             if self.hook:
                 self.hook("begin", l)
             be.layer(tasks)
             gathered = self._exchange(partials)
             for g in range(G):
-                be.finalize(self.graphs[g], gathered[g], self.n_loc, outs[g], e0 if l == 0 else sums[g], sums[g],
-                            flags, self.slope)
+                be.finalize(self.graphs[g], gathered[g], self.n_loc, outs[g], tasks[g]["acc_in"], tasks[g]["acc_out"],
+                            flags, self.slope, x=tasks[g]["x"])
             if self.hook:
                 self.hook("end", l)
             prev = outs
@@ -180,7 +190,7 @@ def bench_sharded(args, rank: int, world: int, device) -> None:
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

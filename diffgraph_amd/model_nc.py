@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from ._lib import DG_D, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE
+from ._lib import DG_ACC_REBUILD, DG_D, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE
 from .diffusion import Denoise, GaussianDiffusion
 from .layers import UUGCNLayer
 
@@ -59,8 +59,13 @@ class HGDM(nn.Module):
             for g, graph in enumerate(he_adjs):
                 e_out = None if last else torch.empty_like(embed)
                 flags = (DG_IN_PRESCALED if l > 0 else 0) | (0 if last else DG_OUT_PRESCALE | DG_OUT_NORM)
-                tasks.append(ops.LayerTask(graph, embed if l == 0 else prev[g], e_out, embed if l == 0 else sums[g],
-                                           sums[g], flags, slope))
+                if l == 0 and L >= 2:      # no running sum from the first layer; the second rebuilds it
+                    acc_in = acc_out = None
+                elif l == 1:
+                    acc_in, acc_out, flags = embed, sums[g], flags | DG_ACC_REBUILD
+                else:
+                    acc_in, acc_out = (embed if l == 0 else sums[g]), sums[g]
+                tasks.append(ops.LayerTask(graph, embed if l == 0 else prev[g], e_out, acc_in, acc_out, flags, slope))
                 prev[g] = e_out
             # graphs that share a handle cannot share a launch (one hub slab per handle)
             seen, batch = set(), []

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
+from ._lib import DG_ACC_REBUILD, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
 from .diffusion import Denoise, GaussianDiffusion
 from .layers import DGLLayer
 
@@ -128,8 +128,15 @@ class HGDM(nn.Module):
             for g, graph in enumerate(graphs):
                 e_out = None if (last and not keep) else torch.empty_like(e0)
                 flags = (DG_IN_PRESCALED if l > 0 else 0) | (0 if last else DG_OUT_PRESCALE)
-                tasks.append(ops.LayerTask(graph, e0 if l == 0 else prev[g], e_out, e0 if l == 0 else sums[g], sums[g],
-                                           flags, slope))
+                # with L >= 2 the first layer writes no running sum; the second rebuilds e0 + normalize(E_1)
+                # from e0 and the stored first-layer activation (see DG_ACC_REBUILD)
+                if l == 0 and L >= 2:
+                    acc_in = acc_out = None
+                elif l == 1:
+                    acc_in, acc_out, flags = e0, sums[g], flags | DG_ACC_REBUILD
+                else:
+                    acc_in, acc_out = (e0 if l == 0 else sums[g]), sums[g]
+                tasks.append(ops.LayerTask(graph, e0 if l == 0 else prev[g], e_out, acc_in, acc_out, flags, slope))
                 prev[g] = e_out
                 saved[g].append(e_out)
             hook = getattr(self, "layer_hook", None)

@@ -92,7 +92,11 @@ int dg_spmm_norm_act_fwd(dg_graph *g, const float *x, float *y, int32_t d, float
  * call with DG_OUT_PRESCALE), so the gather is a plain sum.
  * All tasks run in ONE launch (plus one for hub-row partial sums when any graph has them).
  * ---------------------------------------------------------------------------------- */
-enum { DG_IN_PRESCALED = 1, DG_OUT_NORM = 2, DG_OUT_PRESCALE = 4 };
+enum { DG_IN_PRESCALED = 1, DG_OUT_NORM = 2, DG_OUT_PRESCALE = 4, DG_ACC_REBUILD = 16 };
+/* DG_ACC_REBUILD (second layer only, needs DG_IN_PRESCALED): the first layer did not write a
+ * running sum; acc_in points at the layer-0 table e0 and the sum so far is rebuilt per row as
+ * e0[i] + normalize(x[i])  (x[i] = dinv_src[i] * E_1[i], so normalize(x[i]) is the first
+ * layer's normalised activation).  Saves one table write and one cold table read per graph. */
 
 typedef struct dg_layer_task {
   dg_graph *graph;
@@ -117,8 +121,10 @@ int dg_gcn_layer_fwd(const dg_layer_task *tasks, int32_t n_tasks, int32_t d, voi
  * gathered from the ranks) and apply the epilogue of dg_gcn_layer_fwd (norm of the receiving
  * node, LeakyReLU, normalise, layer sum, next layer's input) with the same flags. */
 int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_parts,
-                            int32_t row_begin, int32_t n_rows, float *e_out, const float *acc_in,
-                            float *acc_out, int32_t flags, float slope, int32_t d, void *stream);
+                            int32_t row_begin, int32_t n_rows, const float *x_prev, float *e_out,
+                            const float *acc_in, float *acc_out, int32_t flags, float slope,
+                            int32_t d, void *stream);   /* x_prev: the layer's gather source, read only
+                                                           under DG_ACC_REBUILD (may be NULL otherwise) */
 
 /* ------------------------------------------------------------------------------------
  * a11: backward of one fused propagation layer, batched over graphs.  Replaces what

@@ -6,7 +6,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
-from diffgraph_amd._lib import DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE
+from diffgraph_amd._lib import DG_ACC_REBUILD, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE
 
 
 class CpuBackend:
@@ -19,11 +19,14 @@ class CpuBackend:
         return torch.full((rows, 64), float("nan"))
 
     @staticmethod
-    def _epilogue(g, rows, s, e_out, acc_in, acc_out, flags, slope):
+    def _epilogue(g, rows, s, e_out, acc_in, acc_out, flags, slope, x=None):
         y = F.leaky_relu(s * g.dinv[rows], slope)
         yn = F.normalize(y, p=2, dim=1)
         if acc_out is not None:
-            acc_out[rows] = acc_in[rows] + yn
+            a = acc_in[rows]
+            if flags & DG_ACC_REBUILD:  # e0 + normalize(E_1), E_1 recovered from the stored dinv * E_1
+                a = a + F.normalize(x[rows] / g.dinv[rows], p=2, dim=1)
+            acc_out[rows] = a + yn
         if e_out is not None:
             e = yn if flags & DG_OUT_NORM else y
             e_out[rows] = e * g.dinv[rows] if flags & DG_OUT_PRESCALE else e
@@ -37,14 +40,14 @@ class CpuBackend:
             if t["partial_out"] is not None:
                 t["partial_out"].copy_(s[pf:])
             rows = slice(0, pf)
-            self._epilogue(g, rows, s[rows], t["e_out"], t["acc_in"], t["acc_out"], t["flags"], t["slope"])
+            self._epilogue(g, rows, s[rows], t["e_out"], t["acc_in"], t["acc_out"], t["flags"], t["slope"], x)
 
-    def finalize(self, g, partials, row_begin, e_out, acc_in, acc_out, flags, slope):
+    def finalize(self, g, partials, row_begin, e_out, acc_in, acc_out, flags, slope, x=None):
         s = torch.zeros_like(partials[0])
         for p in range(partials.shape[0]):
             s = s + partials[p]
         rows = slice(row_begin, row_begin + partials.shape[1])
-        self._epilogue(g, rows, s, e_out, acc_in, acc_out, flags, slope)
+        self._epilogue(g, rows, s, e_out, acc_in, acc_out, flags, slope, x)
 
     def sum_tables(self, tables):
         out = tables[0]
