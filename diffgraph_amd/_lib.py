@@ -62,7 +62,7 @@ SIGNATURES = {
     "dg_spmm_norm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int,
                                        C.c_void_p]),
     "dg_gcn_layer_fwd": (C.c_int, [C.POINTER(LayerTask), C.c_int32, C.c_int32, C.c_void_p]),
-    "dg_gcn_partial_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+    "dg_gcn_partial_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "dg_gcn_layer_bwd": (C.c_int, [C.POINTER(BwdTask), C.c_int32, C.c_int32, C.c_void_p]),
     "dg_sum_tables": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),

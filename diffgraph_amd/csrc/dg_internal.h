@@ -13,6 +13,7 @@
 #define DG_ERR_SIZE (-3)
 
 #define DG_EPI_BWD 0x100  // internal flag: backward epilogue
+#define DG_LDS_MAX_ROWS 383  // small-side rows kept in LDS (+1 zero row) = 96 KiB
 
 // Records a printf-style message retrievable through dg_last_error(); returns `code`.
 int dg_fail(int code, const char *fmt, ...);
@@ -39,6 +40,13 @@ struct dg_csr {
   int32_t *hub_desc = nullptr;   // [n_hub][4] row, first slab row, last slab row + 1, 0
   int32_t *seg_desc = nullptr;   // [n_seg][2] colidx begin, end of each hub-row segment
   int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0;
+  // Bipartite graphs whose second block is small enough for LDS (Industry shape: 1M users x 361
+  // items): rows [0, lds_split) gather only from rows [lds_split, n), whose table (<= 96 KB)
+  // lds_rows_kernel keeps in LDS; those rows are then left out of the three classes above.
+  int32_t lds_split = 0;
+  // [lds_split][16] words = 32 halfwords per row below the split: halfword 0 the degree, 1..31 the
+  // first 31 neighbours as ids relative to the split (padding = n - lds_split, the zero row).
+  uint32_t *lhead = nullptr;
 };
 
 struct dg_graph {
@@ -56,6 +64,8 @@ struct dg_graph {
 
 // Device-visible description of one graph's share of a batched layer launch.
 struct dg_task_dev {
+  const int32_t *rowptr;
+  const uint32_t *lhead;
   const int32_t *colidx, *head, *wave_desc, *hub_desc, *seg_desc;
   const float *colscale, *head_scale;
   const float *dinv_row;     // norm of the receiving (row) node
@@ -72,6 +82,9 @@ struct dg_task_dev {
   int32_t n, n_hub, n_wave, n_group, n_seg;
   int32_t flags;
   float slope;
+  int32_t lds_split;      // > 0: rows below it are summed by lds_rows_kernel
+  int32_t lds_blk_begin, lds_blk_count;  // this task's workgroups in the lds_rows_kernel launch
+  const float *dinv_gather;  // norm of a gathered node (by node id), for staging the LDS table
   int32_t blk_begin;      // first block of this task in the main launch
   int32_t hub_blk_begin;  // first block of this task in the hub-row reduce launch
 };

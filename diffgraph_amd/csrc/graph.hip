@@ -35,7 +35,8 @@ constexpr int kHead = 13;  // neighbour ids carried in a group row's 16-word hea
 struct HostCsr {
   std::vector<int32_t> rowptr, colidx, row_order, head, wave_desc, hub_desc, seg_desc;
   std::vector<float> colscale, head_scale;
-  int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0;
+  std::vector<uint32_t> lhead;
+  int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0, lds_split = 0;
 };
 
 // CSR over `row` with ascending `col` inside each row: two stable counting sorts
@@ -64,15 +65,53 @@ void build_csr(int32_t n, int64_t nnz, const int32_t *row, const int32_t *col, H
   for (int32_t i = 0; i <= n; ++i) out.rowptr[i] = (int32_t)rp[i];
 }
 
+// Finds s such that every edge joins a row < s with a row >= s (the block form
+// [[0,R],[R^T,0]] the reference's makeBiAdj builds); 0 if the graph is not of that form.
+int32_t bipartite_split(int32_t n, const HostCsr &c) {
+  int32_t s = n;
+  for (int32_t r = 0; r < n; ++r) {
+    if (c.rowptr[r + 1] == c.rowptr[r]) continue;
+    int32_t lo = c.colidx[c.rowptr[r]];  // columns ascend inside a row
+    if (lo > r) s = std::min(s, lo);
+  }
+  if (s <= 0 || s >= n) return 0;
+  for (int32_t r = 0; r < n; ++r) {
+    if (c.rowptr[r + 1] == c.rowptr[r]) continue;
+    int32_t lo = c.colidx[c.rowptr[r]], hi = c.colidx[c.rowptr[r + 1] - 1];
+    if (r < s ? lo < s : hi >= s) return 0;
+  }
+  return s;
+}
+
 // Rows ordered hub | wave | group, each class by falling degree (ties: rising row id), so
 // the longest work starts first and the four rows sharing a wavefront have like lengths.
+// Rows below c.lds_split (if set) are left to lds_rows_kernel and appear in no class.
 void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c) {
   std::vector<int32_t> deg(n);
   for (int32_t i = 0; i < n; ++i) deg[i] = c.rowptr[i + 1] - c.rowptr[i];
-  c.row_order.resize(n);
-  std::iota(c.row_order.begin(), c.row_order.end(), 0);
+  c.lds_split = 0;
+  {
+    const int32_t s = bipartite_split(n, c);
+    // worth it only when the large side is much larger than the LDS-resident side
+    if (s > 0 && n - s <= DG_LDS_MAX_ROWS && s >= 64 * (n - s)) c.lds_split = s;
+  }
+  c.lhead.clear();
+  if (c.lds_split > 0) {
+    const uint32_t pad = (uint32_t)(n - c.lds_split);  // the zero row of the LDS table
+    c.lhead.assign((size_t)c.lds_split * 16, pad | (pad << 16));
+    for (int32_t r = 0; r < c.lds_split; ++r) {
+      uint16_t hw[32];
+      for (int k = 0; k < 32; ++k) hw[k] = (uint16_t)pad;
+      hw[0] = (uint16_t)std::min(deg[r], 65535);
+      for (int32_t k = 0; k < std::min(deg[r], 31); ++k) hw[k + 1] = (uint16_t)(c.colidx[c.rowptr[r] + k] - c.lds_split);
+      for (int k = 0; k < 16; ++k) c.lhead[(size_t)r * 16 + k] = (uint32_t)hw[2 * k] | ((uint32_t)hw[2 * k + 1] << 16);
+    }
+  }
+  c.row_order.clear();
+  for (int32_t i = c.lds_split; i < n; ++i) c.row_order.push_back(i);
   std::stable_sort(c.row_order.begin(), c.row_order.end(),
                    [&](int32_t a, int32_t b) { return deg[a] > deg[b]; });
+  n = (int32_t)c.row_order.size();  // rows scheduled in the three classes
   c.n_hub = c.n_wave = c.n_group = 0;
   for (int32_t k = 0; k < n; ++k) {
     int32_t d = deg[c.row_order[k]];
@@ -133,14 +172,16 @@ hipError_t upload_csr(const HostCsr &h, dg_csr &d) {
   if ((e = upload(h.wave_desc, &d.wave_desc)) != hipSuccess) return e;
   if ((e = upload(h.hub_desc, &d.hub_desc)) != hipSuccess) return e;
   if ((e = upload(h.seg_desc, &d.seg_desc)) != hipSuccess) return e;
+  if ((e = upload(h.lhead, &d.lhead)) != hipSuccess) return e;
   d.n_hub = h.n_hub; d.n_wave = h.n_wave; d.n_group = h.n_group; d.n_seg = h.n_seg;
+  d.lds_split = h.lds_split;
   return hipSuccess;
 }
 
 void free_csr(dg_csr &d) {
   (void)hipFree(d.rowptr); (void)hipFree(d.colidx); (void)hipFree(d.colscale); (void)hipFree(d.row_order);
   (void)hipFree(d.head); (void)hipFree(d.head_scale); (void)hipFree(d.wave_desc); (void)hipFree(d.hub_desc);
-  (void)hipFree(d.seg_desc);
+  (void)hipFree(d.seg_desc); (void)hipFree(d.lhead);
   d = dg_csr();
 }
 
@@ -234,13 +275,13 @@ extern "C" int dg_graph_export(const dg_graph *g, int which, void *dst, size_t b
   if (!g || !dst) return dg_fail(DG_ERR_ARG, "dg_graph_export: NULL argument");
   const void *src = nullptr;
   size_t need = 0;
-  int32_t counts[4] = {g->fwd.n_hub, g->fwd.n_wave, g->fwd.n_group, g->fwd.n_seg};
+  int32_t counts[5] = {g->fwd.n_hub, g->fwd.n_wave, g->fwd.n_group, g->fwd.n_seg, g->fwd.lds_split};
   switch (which) {
     case 0: src = g->fwd.rowptr; need = ((size_t)g->n + 1) * 4; break;
     case 1: src = g->fwd.colidx; need = (size_t)g->nnz * 4; break;
     case 2: src = g->dinv_src; need = (size_t)g->n * 4; break;
     case 3: src = g->dinv_dst; need = (size_t)g->n * 4; break;
-    case 4: src = g->fwd.row_order; need = (size_t)g->n * 4; break;
+    case 4: src = g->fwd.row_order; need = (size_t)(g->n - g->fwd.lds_split) * 4; break;
     case 5:
       if (bytes < sizeof(counts)) return dg_fail(DG_ERR_SIZE, "dg_graph_export: buffer too small");
       memcpy(dst, counts, sizeof(counts));

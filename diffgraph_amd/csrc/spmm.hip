@@ -25,6 +25,10 @@
 // into an out-of-range offset, which the hardware answers with zeros and no memory access.
 #include "dg_internal.h"
 
+#include <algorithm>
+#include <climits>
+#include <cmath>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -102,46 +106,52 @@ __device__ __forceinline__ f32x4 add_groups(f32x4 v) {  // (g0+g1)+(g2+g3), same
   return v + o;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// Sum over the 16 lanes of a group, left in every lane: two quad permutes, then the 8-lane and
+// 16-lane mirrors (after the quad steps all lanes of a quad agree, so mirroring pairs the right
+// partial sums).  Four VALU instructions; no LDS crossbar traffic.
 __device__ __forceinline__ float sum16(float v) {
-  v += __shfl_xor(v, 8, 16);
-  v += __shfl_xor(v, 4, 16);
-  v += __shfl_xor(v, 2, 16);
-  v += __shfl_xor(v, 1, 16);
+  v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);  // row_half_mirror
+  v += dpp_f<0x140>(v);  // row_mirror
   return v;
 }
+
+// 1 / max(sqrt(ss), 1e-12): the factor F.normalize divides by, from the hardware reciprocal
+// square root (1 ulp), so the normalised row is within ~2 ulp of the reference's division.
+__device__ __forceinline__ float inv_norm(float ss) { return fminf(__builtin_amdgcn_rsqf(ss), 1e12f); }
 
 // What the epilogue needs from memory; asked for before the neighbour rows so that it
 // arrives while they load.
 struct row_ctx {
-  float di, dout;
-  f32x4 a_in;  // forward: running layer sum; backward: saved activation
-  f32x4 g_in;  // backward: gradient wrt the layer sum
+  float di, dsrc;
+  f32x4 a_in;  // forward: running layer sum (or e0 under DG_ACC_REBUILD); backward: saved activation
+  f32x4 g_in;  // backward: gradient wrt the layer sum; forward under DG_ACC_REBUILD: the row's own x
 };
 
+// Loads only -- no arithmetic on the loaded values here, so that the requests stay in flight
+// while the caller gathers the neighbour rows (or works on the previous row).
 __device__ __forceinline__ row_ctx load_row_ctx(const dg_task_dev &T, int row, int l) {
   row_ctx c;
   const size_t o = (size_t)row * (DG_D / 4) + l;
   c.di = T.dinv_row[row];
+  c.dsrc = T.dinv_out[row];
   c.a_in = f32x4{0.f, 0.f, 0.f, 0.f};
   c.g_in = c.a_in;
   if (T.flags & DG_EPI_BWD) {
-    c.dout = T.dinv_out[row];
     if (T.e_saved) {
       c.a_in = reinterpret_cast<const f32x4 *>(T.e_saved)[o];
       c.g_in = reinterpret_cast<const f32x4 *>(T.d_sum)[o];
     }
     return c;
   }
-  const float dsrc = (T.flags & (DG_OUT_PRESCALE | DG_ACC_REBUILD)) ? T.dinv_out[row] : 1.0f;
-  c.dout = (T.flags & DG_OUT_PRESCALE) ? dsrc : 1.0f;
   if (T.acc_out) c.a_in = reinterpret_cast<const f32x4 *>(T.acc_in)[o];
-  if (T.flags & DG_ACC_REBUILD) {  // a_in = e0[i] + normalize(E_1[i]) from the stored dinv_src[i] * E_1[i]
-    const f32x4 p = reinterpret_cast<const f32x4 *>(T.x)[o];
-    const float np_ = sqrtf(sum16(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w));
-    // ||E_1|| = np_ / dsrc; F.normalize divides by max(||E_1||, 1e-12)
-    const float inv = (np_ > 1e-12f * dsrc) ? 1.0f / np_ : 1.0f / (1e-12f * dsrc);
-    c.a_in += p * inv;
-  }
+  if (T.flags & DG_ACC_REBUILD) c.g_in = reinterpret_cast<const f32x4 *>(T.x)[o];
   return c;
 }
 
@@ -173,7 +183,7 @@ __device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, cons
   dz.y = e.y > 0.f ? dE.y : dE.y * slope;
   dz.z = e.z > 0.f ? dE.z : dE.z * slope;
   dz.w = e.w > 0.f ? dE.w : dE.w * slope;
-  reinterpret_cast<f32x4 *>(T.e_out)[o] = dz * rc.dout;
+  reinterpret_cast<f32x4 *>(T.e_out)[o] = dz * rc.dsrc;
 }
 
 // rst*norm, LeakyReLU, F.normalize, layer sum, next layer's input (Model.py:165-172,67-70).
@@ -194,14 +204,20 @@ __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const ro
   f32x4 yn = y;
   if (want_norm) {
     float ss = sum16(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
-    // one correctly rounded reciprocal per row, then multiplies: within 1 ulp of F.normalize's division
-    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-    yn = y * inv;
+    yn = y * inv_norm(ss);
   }
-  if (T.acc_out) reinterpret_cast<f32x4 *>(T.acc_out)[o] = rc.a_in + yn;
+  if (T.acc_out) {
+    f32x4 a = rc.a_in;
+    if (T.flags & DG_ACC_REBUILD) {  // a = e0[i] + normalize(E_1[i]) from the stored p = dinv_src[i] * E_1[i]:
+      const f32x4 p = rc.g_in;       // ||E_1|| = ||p|| / dsrc, so normalize(E_1) = p / max(||p||, 1e-12 * dsrc)
+      const float ps = sum16(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w);
+      a += p * fminf(__builtin_amdgcn_rsqf(ps), 1e12f * __builtin_amdgcn_rcpf(rc.dsrc));
+    }
+    reinterpret_cast<f32x4 *>(T.acc_out)[o] = a + yn;
+  }
   if (T.e_out) {
     f32x4 e = (T.flags & DG_OUT_NORM) ? yn : y;
-    if (T.flags & DG_OUT_PRESCALE) e *= rc.dout;
+    if (T.flags & DG_OUT_PRESCALE) e *= rc.dsrc;
     reinterpret_cast<f32x4 *>(T.e_out)[o] = e;
   }
 }
@@ -282,7 +298,8 @@ __global__ __launch_bounds__(256) void hub_reduce_kernel(const dg_task_batch bat
 // Row-sharded layer, second half: sum the ranks' partial neighbour sums of a row in rank
 // order, then the usual epilogue.  16 lanes per row.
 __global__ __launch_bounds__(256) void partial_finalize_kernel(const dg_task_dev T, const float *__restrict__ partials,
-                                                               int n_parts, int row_begin, int n_rows) {
+                                                               int n_parts, int64_t part_stride, int row_begin,
+                                                               int n_rows) {
   const int l = threadIdx.x & 15;
   const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (r >= n_rows) return;
@@ -290,8 +307,118 @@ __global__ __launch_bounds__(256) void partial_finalize_kernel(const dg_task_dev
   const row_ctx rc = load_row_ctx(T, row, l);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int p = 0; p < n_parts; ++p)
-    acc += reinterpret_cast<const f32x4 *>(partials)[((size_t)p * n_rows + r) * (DG_D / 4) + l];
+    acc += reinterpret_cast<const f32x4 *>(partials)[((size_t)p * part_stride + r) * (DG_D / 4) + l];
   epilogue(T, row, rc, acc, l);
+}
+
+// Rows [0, lds_split) of a bipartite graph whose other block fits in LDS (see dg_csr::lds_split).
+// A 1024-thread workgroup copies that block's table rows (times their source norm unless the
+// table is already scaled) into LDS once, then walks its share of the rows: 64 rows at a time,
+// one 16-lane group per row.  A row's degree and first 31 neighbours come in one 64-B record of
+// 16-bit ids; neighbour rows are read with ds_read_b128 (four rows per wavefront instruction;
+// 256-B aligned rows make every 16-lane read group conflict-free).  The next row's record and
+// epilogue inputs are requested before the current row is summed, so the loop has no exposed
+// global-memory latency.  Rows are taken in natural order: outputs stream out in full lines.
+__global__ __launch_bounds__(1024) void lds_rows_kernel(const dg_task_batch batch) {
+  extern __shared__ f32x4 tab[];  // [(n - split) + 1][16]; the last row is zeros (padding neighbour)
+  int ti = 0;
+  for (int k = 0; k < batch.n_tasks; ++k)
+    if (batch.t[k].lds_blk_count > 0 && (int)blockIdx.x >= batch.t[k].lds_blk_begin) ti = k;
+  const dg_task_dev &T = batch.t[ti];
+  const int split = T.lds_split, n_small = T.n - split;
+  const bool scale = !(T.flags & DG_IN_PRESCALED);
+  for (int i = threadIdx.x; i < (n_small + 1) * 16; i += blockDim.x) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int r = i >> 4;
+    if (r < n_small) {
+      v = reinterpret_cast<const f32x4 *>(T.x)[(size_t)(split + r) * 16 + (i & 15)];
+      if (scale) v *= T.dinv_gather[split + r];
+    }
+    tab[i] = v;
+  }
+  __syncthreads();
+  const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+  // Each workgroup takes tiles of 64*R consecutive rows; a group owns R of them, 64 apart, and
+  // asks for the next tile's records and epilogue inputs before summing the current tile, so
+  // R rows' worth of requests per group are in flight (the workgroup is alone on its CU).
+  constexpr int R = 4;
+  const int stride = T.lds_blk_count * 64 * R;
+  const f32x4 *t = tab + l;
+  int base = (blockIdx.x - T.lds_blk_begin) * 64 * R + g;
+  unsigned w_next[R];
+  row_ctx rc_next[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    w_next[j] = 0;
+    rc_next[j] = row_ctx{};
+    const int row = base + 64 * j;
+    if (row < split) {
+      w_next[j] = T.lhead[(size_t)row * 16 + l];
+      rc_next[j] = load_row_ctx(T, row, l);
+    }
+  }
+  for (; base < split; base += stride) {
+    unsigned w_cur[R];
+    row_ctx rc_cur[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      w_cur[j] = w_next[j];
+      rc_cur[j] = rc_next[j];
+      const int row = base + stride + 64 * j;
+      if (row < split) {
+        w_next[j] = T.lhead[(size_t)row * 16 + l];
+        rc_next[j] = load_row_ctx(T, row, l);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int row = base + 64 * j;
+      if (row >= split) continue;
+      const unsigned w = w_cur[j];
+      const int deg = bcast16<0>((int)w) & 0xffff;
+      // slot 0 of the record is the degree, not a neighbour: read the zero row for it
+      const unsigned ww = l == 0 ? ((w & 0xffff0000u) | (unsigned)n_small) : w;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#define DG_LDS4(J)                                                                                    \
+      {                                                                                               \
+        const unsigned a = (unsigned)bcast16<2 * (J)>((int)ww), b = (unsigned)bcast16<2 * (J) + 1>((int)ww); \
+        const f32x4 v0 = t[(a & 0xffffu) * 16], v1 = t[(a >> 16) * 16];                               \
+        const f32x4 v2 = t[(b & 0xffffu) * 16], v3 = t[(b >> 16) * 16];                               \
+        acc += v0; acc += v1; acc += v2; acc += v3;                                                   \
+      }
+      DG_LDS4(0)
+      if (deg >= 4) DG_LDS4(1)
+      if (deg >= 8) DG_LDS4(2)
+      if (deg >= 12) DG_LDS4(3)
+      if (deg >= 16) {
+        DG_LDS4(4)
+        if (deg >= 20) DG_LDS4(5)
+        if (deg >= 24) DG_LDS4(6)
+        if (deg >= 28) DG_LDS4(7)
+      }
+#undef DG_LDS4
+      if (deg > 31) {  // rare: the rest of the list from the CSR
+        const int e = T.rowptr[row + 1];
+        for (int p = T.rowptr[row] + 31; p < e; p += 16) {
+          int c = n_small;
+          if (p + l < e) c = T.colidx[p + l] - split;
+          const int cnt = e - p;
+#define DG_LDS4T(K0)                                                                                  \
+          {                                                                                           \
+            const f32x4 v0 = t[bcast16<K0>(c) * 16], v1 = t[bcast16<K0 + 1>(c) * 16];                 \
+            const f32x4 v2 = t[bcast16<K0 + 2>(c) * 16], v3 = t[bcast16<K0 + 3>(c) * 16];             \
+            acc += v0; acc += v1; acc += v2; acc += v3;                                               \
+          }
+          DG_LDS4T(0)
+          if (cnt > 4) DG_LDS4T(4)
+          if (cnt > 8) DG_LDS4T(8)
+          if (cnt > 12) DG_LDS4T(12)
+#undef DG_LDS4T
+        }
+      }
+      epilogue(T, row, rc_cur[j], acc, l);
+    }
+  }
 }
 
 // Rows with nothing to gather (last layer of the backward pass): epilogue only, 16 lanes per row.
@@ -328,6 +455,8 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   if ((in.flags & DG_ACC_REBUILD) && (!(in.flags & DG_IN_PRESCALED) || !in.acc_out))
     return dg_fail(DG_ERR_ARG, "layer task: DG_ACC_REBUILD needs DG_IN_PRESCALED and acc_in/acc_out");
   const dg_csr &c = transpose ? g->bwd : g->fwd;
+  o.rowptr = c.rowptr; o.lhead = c.lhead; o.lds_split = c.lds_split; o.lds_blk_begin = 0; o.lds_blk_count = 0;
+  o.dinv_gather = transpose ? g->dinv_dst : g->dinv_src;
   o.colidx = c.colidx; o.head = c.head; o.wave_desc = c.wave_desc; o.hub_desc = c.hub_desc; o.seg_desc = c.seg_desc;
   o.colscale = c.colscale; o.head_scale = c.head_scale;
   o.dinv_row = transpose ? g->dinv_src : g->dinv_dst;
@@ -353,7 +482,43 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     blocks += ((t.n_seg + 3) >> 2) + ((t.n_wave + 3) >> 2) + ((t.n_group + 15) >> 4);
     hub_blocks += (t.n_hub + 3) >> 2;
   }
+  // workgroups of the LDS-table kernel: one per CU in total, shared out by the tasks' edge counts
+  int32_t lds_blocks = 0, lds_rows_max = 0;
+  {
+    double w[DG_MAX_TASKS], wsum = 0;
+    for (int k = 0; k < n_tasks; ++k) {
+      // a row costs its streamed record/inputs/outputs (~0.8 KB from HBM) plus one LDS row read per edge,
+      // which is worth about 1/50 of that
+      w[k] = batch.t[k].lds_split > 0 ? 0.5 * (double)graphs[k]->nnz + 48.0 * batch.t[k].lds_split : 0.0;
+      wsum += w[k];
+    }
+    int dev = 0, cus = 256;
+    if (wsum > 0 && hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    for (int k = 0; k < n_tasks; ++k) {
+      dg_task_dev &t = batch.t[k];
+      t.lds_blk_begin = lds_blocks;
+      if (w[k] > 0) {
+        int32_t cnt = std::max(1, (int32_t)std::lround(cus * w[k] / wsum));
+        cnt = std::min(cnt, (t.lds_split + 63) / 64);
+        t.lds_blk_count = cnt;
+        lds_blocks += cnt;
+        lds_rows_max = std::max(lds_rows_max, t.n - t.lds_split);
+      } else {
+        t.lds_blk_count = 0;
+      }
+    }
+  }
   for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
+  if (lds_blocks > 0) {
+    const size_t lds_bytes = (size_t)(lds_rows_max + 1) * DG_D * sizeof(float);
+    static bool lds_attr_set = false;  // more than 64 KiB of dynamic LDS has to be opted into once
+    if (!lds_attr_set) {
+      DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_rows_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (DG_LDS_MAX_ROWS + 1) * DG_D * (int)sizeof(float)));
+      lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(lds_rows_kernel, dim3(lds_blocks), dim3(1024), lds_bytes, stream, batch);
+  }
   if (blocks > 0) hipLaunchKernelGGL(gcn_layer_kernel, dim3(blocks), dim3(256), 0, stream, batch);
   if (hub_blocks > 0) hipLaunchKernelGGL(hub_reduce_kernel, dim3(hub_blocks), dim3(256), 0, stream, batch);
   DG_HIP(hipGetLastError());
@@ -391,11 +556,12 @@ extern "C" int dg_spmm_norm_act_fwd(dg_graph *g, const float *x, float *y, int32
   return launch_layer(&t, 1, transpose, (hipStream_t)stream);
 }
 
-extern "C" int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_parts, int32_t row_begin,
-                                       int32_t n_rows, const float *x_prev, float *e_out, const float *acc_in,
+extern "C" int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_parts,
+                                       int64_t part_stride_rows, int32_t row_begin, int32_t n_rows, const float *x_prev, float *e_out, const float *acc_in,
                                        float *acc_out, int32_t flags, float slope, int32_t d, void *stream) {
   if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_gcn_partial_finalize: embedding width %d unsupported (built for %d)", d, DG_D);
   if (!graph || !partials || n_parts <= 0) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: NULL argument");
+  if (part_stride_rows < n_rows) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: part stride smaller than a part");
   if (row_begin < 0 || n_rows < 0 || (int64_t)row_begin + n_rows > graph->n)
     return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: rows [%d,%d) outside the graph's %d nodes", row_begin,
                    row_begin + n_rows, graph->n);
@@ -408,7 +574,7 @@ extern "C" int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, i
   int rc = fill_task(lt, 0, t);
   if (rc) return rc;
   hipLaunchKernelGGL(partial_finalize_kernel, dim3((n_rows + 15) >> 4), dim3(256), 0, (hipStream_t)stream, t, partials,
-                     n_parts, row_begin, n_rows);
+                     n_parts, part_stride_rows, row_begin, n_rows);
   DG_HIP(hipGetLastError());
   return 0;
 }

@@ -103,19 +103,23 @@ class ShardedRecPropagation:
         self.hook = None
 
     def _exchange(self, partials: torch.Tensor) -> torch.Tensor:
-        """[G, n_item, 64] on every rank -> [G, world, n_item, 64] (partial sums in rank order)."""
+        """[G, n_item, 64] on every rank -> [world, G, n_item, 64] (partial sums in rank order)."""
         if self.world == 1:
-            return partials.unsqueeze(1)
+            return partials.unsqueeze(0)
         import torch.distributed as dist
         if partials.is_cuda and dist.get_backend(self.group) == "gloo":
             # single-GPU rehearsal of the multi-process path: gloo moves host memory
             host = partials.cpu()
             parts = [torch.empty_like(host) for _ in range(self.world)]
             dist.all_gather(parts, host, group=self.group)
-            return torch.stack(parts, dim=1).contiguous().to(partials.device)
+            return torch.stack(parts, dim=0).to(partials.device)
+        if partials.is_cuda:
+            out = torch.empty((self.world,) + tuple(partials.shape), dtype=partials.dtype, device=partials.device)
+            dist.all_gather_into_tensor(out, partials, group=self.group)   # one RCCL all-gather, no re-packing
+            return out
         parts = [torch.empty_like(partials) for _ in range(self.world)]
         dist.all_gather(parts, partials, group=self.group)
-        return torch.stack(parts, dim=1).contiguous()
+        return torch.stack(parts, dim=0)
 
     def forward(self, e0: torch.Tensor):
         """e0: [n_loc + n_item, 64] = this rank's user rows, then the (replicated) item rows.
@@ -143,7 +147,7 @@ class ShardedRecPropagation:
             be.layer(tasks)
             gathered = self._exchange(partials)
             for g in range(G):
-                be.finalize(self.graphs[g], gathered[g], self.n_loc, outs[g], tasks[g]["acc_in"], tasks[g]["acc_out"],
+                be.finalize(self.graphs[g], gathered[:, g], self.n_loc, outs[g], tasks[g]["acc_in"], tasks[g]["acc_out"],
                             flags, self.slope, x=tasks[g]["x"])
             if self.hook:
                 self.hook("end", l)

@@ -89,9 +89,9 @@ class CSRGraph:
         return self._export(2, self._n, np.float32), self._export(3, self._n, np.float32)
 
     def schedule(self) -> dict:
-        c = self._export(5, 4, np.int32)
-        return {"row_order": self._export(4, self._n, np.int32), "n_hub": int(c[0]), "n_wave": int(c[1]),
-                "n_group": int(c[2]), "n_seg": int(c[3])}
+        c = self._export(5, 5, np.int32)
+        return {"row_order": self._export(4, self._n - int(c[4]), np.int32), "n_hub": int(c[0]), "n_wave": int(c[1]),
+                "n_group": int(c[2]), "n_seg": int(c[3]), "lds_split": int(c[4])}
 
     def close(self) -> None:
         if self._h is not None:

@@ -96,16 +96,17 @@ def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
 
 def gcn_partial_finalize(graph: CSRGraph, partials: torch.Tensor, row_begin: int, e_out, acc_in, acc_out, flags: int,
                          slope: float, x: Optional[torch.Tensor] = None) -> None:
-    """partials: [n_parts, n_rows, 64] partial neighbour sums of rows [row_begin, row_begin+n_rows)."""
+    """partials: [n_parts, n_rows, 64] partial neighbour sums of rows [row_begin, row_begin+n_rows); the parts may
+    be strided (a slice [:, g] of a gathered [n_parts, graphs, n_rows, 64] buffer)."""
     if partials.dim() != 3 or partials.shape[2] != DG_D or partials.dtype != torch.float32 or not partials.is_cuda \
-            or not partials.is_contiguous():
-        raise DiffGraphHipError("partials: expected a contiguous float32 GPU tensor [n_parts, n_rows, 64]")
+            or partials.stride(2) != 1 or partials.stride(1) != DG_D or partials.stride(0) % DG_D != 0:
+        raise DiffGraphHipError("partials: expected a float32 GPU tensor [n_parts, n_rows, 64] with contiguous rows")
     n = graph.num_nodes()
     for nm, v in (("e_out", e_out), ("acc_in", acc_in), ("acc_out", acc_out), ("x", x)):
         if v is not None:
             _table(v, nm, n)
-    rc = _lib.load().dg_gcn_partial_finalize(graph.handle, partials.data_ptr(), partials.shape[0], int(row_begin),
-                                             partials.shape[1], _ptr(x), _ptr(e_out), _ptr(acc_in), _ptr(acc_out), int(flags),
+    rc = _lib.load().dg_gcn_partial_finalize(graph.handle, partials.data_ptr(), partials.shape[0],
+                                             partials.stride(0) // DG_D, int(row_begin), partials.shape[1], _ptr(x), _ptr(e_out), _ptr(acc_in), _ptr(acc_out), int(flags),
                                              float(slope), DG_D, _lib.stream_ptr(partials.device))
     _lib.check(rc, "dg_gcn_partial_finalize")
 

@@ -67,7 +67,9 @@ int64_t dg_graph_num_edges(const dg_graph *g);
 /* 1 if the edge set equals its transpose (then forward and backward share one CSR). */
 int dg_graph_is_symmetric(const dg_graph *g);
 /* Copy schedule/CSR facts back to the host for tests: which = 0 rowptr[n+1], 1 colidx[nnz],
- * 2 dinv_src[n] (float bits), 3 dinv_dst[n], 4 row_order[n], 5 counts {n_hub,n_wave,n_group,n_seg}. */
+ * 2 dinv_src[n] (float bits), 3 dinv_dst[n], 4 row_order[n - lds_split],
+ * 5 counts {n_hub,n_wave,n_group,n_seg,lds_split} (lds_split > 0: rows below it gather from an
+ * LDS-resident copy of the rows above it and are not in row_order). */
 int dg_graph_export(const dg_graph *g, int which, void *dst_host, size_t dst_bytes);
 
 /* ------------------------------------------------------------------------------------
@@ -117,11 +119,13 @@ typedef struct dg_layer_task {
 int dg_gcn_layer_fwd(const dg_layer_task *tasks, int32_t n_tasks, int32_t d, void *stream);
 
 /* Second half of a row-sharded layer: for rows [row_begin, row_begin + n_rows) of `graph`,
- * add the n_parts partial neighbour sums  partials[p][r][64]  (p = 0..n_parts-1 in order,
- * gathered from the ranks) and apply the epilogue of dg_gcn_layer_fwd (norm of the receiving
- * node, LeakyReLU, normalise, layer sum, next layer's input) with the same flags. */
+ * add the n_parts partial neighbour sums (p = 0..n_parts-1 in order, gathered from the ranks;
+ * part p's row r starts at partials + (p * part_stride_rows + r) * 64) and apply the epilogue of
+ * dg_gcn_layer_fwd (norm of the receiving node, LeakyReLU, normalise, layer sum, next layer's
+ * input) with the same flags. */
 int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_parts,
-                            int32_t row_begin, int32_t n_rows, const float *x_prev, float *e_out,
+                            int64_t part_stride_rows, int32_t row_begin, int32_t n_rows,
+                            const float *x_prev, float *e_out,
                             const float *acc_in, float *acc_out, int32_t flags, float slope,
                             int32_t d, void *stream);   /* x_prev: the layer's gather source, read only
                                                            under DG_ACC_REBUILD (may be NULL otherwise) */
