@@ -18,6 +18,7 @@ DG_MAX_TASKS = 8
 DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE = 1, 2, 4
 DG_BWD_SAVED_PRESCALED = 8
 DG_ACC_REBUILD = 16
+DG_BWD_NORM_FEED = 32
 
 
 class DiffGraphHipError(RuntimeError):
@@ -27,12 +28,12 @@ class DiffGraphHipError(RuntimeError):
 class LayerTask(C.Structure):
     _fields_ = [("graph", C.c_void_p), ("x", C.c_void_p), ("e_out", C.c_void_p), ("acc_in", C.c_void_p),
                 ("acc_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float), ("partial_out", C.c_void_p),
-                ("partial_from", C.c_int32)]
+                ("partial_from", C.c_int32), ("row_norm_out", C.c_void_p)]
 
 
 class BwdTask(C.Structure):
     _fields_ = [("graph", C.c_void_p), ("w_in", C.c_void_p), ("e_saved", C.c_void_p), ("d_sum", C.c_void_p),
-                ("w_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float)]
+                ("w_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float), ("row_norm", C.c_void_p)]
 
 
 class Denoiser(C.Structure):

@@ -79,6 +79,7 @@ struct dg_task_dev {
   int32_t partial_from;
   const float *e_saved;  // backward: saved forward activation of this layer (NULL: layer 0)
   const float *d_sum;    // backward: gradient wrt the layer sum
+  float *row_norm;       // forward: ||y|| out (NULL: off); backward with DG_BWD_NORM_FEED: ||y|| in
   int32_t n, n_hub, n_wave, n_group, n_seg;
   int32_t flags;
   float slope;

@@ -129,7 +129,7 @@ __device__ __forceinline__ float inv_norm(float ss) { return fminf(__builtin_amd
 // What the epilogue needs from memory; asked for before the neighbour rows so that it
 // arrives while they load.
 struct row_ctx {
-  float di, dsrc;
+  float di, dsrc, rn;
   f32x4 a_in;  // forward: running layer sum (or e0 under DG_ACC_REBUILD); backward: saved activation
   f32x4 g_in;  // backward: gradient wrt the layer sum; forward under DG_ACC_REBUILD: the row's own x
 };
@@ -143,7 +143,9 @@ __device__ __forceinline__ row_ctx load_row_ctx(const dg_task_dev &T, int row, i
   c.dsrc = T.dinv_out[row];
   c.a_in = f32x4{0.f, 0.f, 0.f, 0.f};
   c.g_in = c.a_in;
+  c.rn = 0.f;
   if (T.flags & DG_EPI_BWD) {
+    if (T.flags & DG_BWD_NORM_FEED) c.rn = T.row_norm[row];
     if (T.e_saved) {
       c.a_in = reinterpret_cast<const f32x4 *>(T.e_saved)[o];
       c.g_in = reinterpret_cast<const f32x4 *>(T.d_sum)[o];
@@ -166,17 +168,19 @@ __device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, cons
   const f32x4 e = rc.a_in, g = rc.g_in;
   const float c = (T.flags & DG_BWD_SAVED_PRESCALED) ? rc.di : 1.0f;  // e = c * E_l
   const float re = sqrtf(sum16(e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w));
-  const float r = re / c;                                              // ||E_l||
+  const bool feed = (T.flags & DG_BWD_NORM_FEED) != 0;  // e is the normalised activation; its length was saved
+  const float r = feed ? rc.rn : re / c;                // ||y_l||
+  const f32x4 gt = feed ? g + G : g;                    // what reaches the normalisation from above
   f32x4 dE;
   if (r > 1e-12f) {  // y/||y||: d = (g - n (n.g)) / ||y||
     const float inv_re = 1.0f / re, inv_r = 1.0f / r;
     const f32x4 n = e * inv_re;
-    const float ng = sum16(n.x * g.x + n.y * g.y + n.z * g.z + n.w * g.w);
-    dE = (g - n * ng) * inv_r;
+    const float ng = sum16(n.x * gt.x + n.y * gt.y + n.z * gt.z + n.w * gt.w);
+    dE = (gt - n * ng) * inv_r;
   } else {           // clamp_min(norm, eps) is active: y / eps
-    dE = g * 1e12f;
+    dE = gt * 1e12f;
   }
-  dE += G;
+  if (!feed) dE += G;
   const float slope = T.slope;
   f32x4 dz;
   dz.x = e.x > 0.f ? dE.x : dE.x * slope;
@@ -205,6 +209,7 @@ __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const ro
   if (want_norm) {
     float ss = sum16(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
     yn = y * inv_norm(ss);
+    if (T.row_norm && l == 0) T.row_norm[row] = sqrtf(ss);
   }
   if (T.acc_out) {
     f32x4 a = rc.a_in;
@@ -466,6 +471,7 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   o.flags = in.flags; o.slope = in.slope;
   o.e_saved = nullptr; o.d_sum = nullptr;
   o.partial_out = in.partial_out; o.partial_from = in.partial_from;
+  o.row_norm = in.row_norm_out;
   return 0;
 }
 
@@ -552,7 +558,7 @@ extern "C" int dg_spmm_norm_act_fwd(dg_graph *g, const float *x, float *y, int32
   if (!g || !x || !y) return dg_fail(DG_ERR_ARG, "dg_spmm_norm_act_fwd: NULL argument");
   dg_layer_task t;
   t.graph = g; t.x = x; t.e_out = y; t.acc_in = nullptr; t.acc_out = nullptr; t.flags = 0; t.slope = slope;
-  t.partial_out = nullptr; t.partial_from = 0;
+  t.partial_out = nullptr; t.partial_from = 0; t.row_norm_out = nullptr;
   return launch_layer(&t, 1, transpose, (hipStream_t)stream);
 }
 
@@ -569,7 +575,7 @@ extern "C" int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, i
   if ((flags & DG_ACC_REBUILD) && !x_prev) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: DG_ACC_REBUILD needs x_prev");
   dg_layer_task lt;
   lt.graph = graph; lt.x = x_prev ? x_prev : partials; lt.e_out = e_out; lt.acc_in = acc_in; lt.acc_out = acc_out;
-  lt.flags = flags; lt.slope = slope; lt.partial_out = nullptr; lt.partial_from = 0;
+  lt.flags = flags; lt.slope = slope; lt.partial_out = nullptr; lt.partial_from = 0; lt.row_norm_out = nullptr;
   dg_task_dev t;
   int rc = fill_task(lt, 0, t);
   if (rc) return rc;
@@ -594,16 +600,20 @@ extern "C" int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32
     if (!b.w_in && !b.e_saved) return dg_fail(DG_ERR_ARG, "backward task %d: neither w_in nor e_saved given", k);
     if (b.e_saved && !b.d_sum) return dg_fail(DG_ERR_ARG, "backward task %d: e_saved needs d_sum", k);
     if (b.w_out == b.w_in) return dg_fail(DG_ERR_ARG, "backward task %d: w_out must not alias w_in", k);
+    if ((b.flags & DG_BWD_NORM_FEED) && b.e_saved && !b.row_norm)
+      return dg_fail(DG_ERR_ARG, "backward task %d: DG_BWD_NORM_FEED needs row_norm", k);
     dg_layer_task lt;
     lt.graph = b.graph; lt.x = b.w_in ? b.w_in : b.w_out; lt.e_out = b.w_out; lt.acc_in = nullptr; lt.acc_out = nullptr;
     lt.flags = DG_IN_PRESCALED | DG_EPI_BWD | (b.flags & DG_BWD_SAVED_PRESCALED); lt.slope = b.slope;
-    lt.partial_out = nullptr; lt.partial_from = 0;
+    if (b.e_saved) lt.flags |= b.flags & DG_BWD_NORM_FEED;
+    lt.partial_out = nullptr; lt.partial_from = 0; lt.row_norm_out = nullptr;
     dg_task_batch &dst = b.w_in ? gather : rowwise;
     dg_task_dev &t = dst.t[dst.n_tasks];
     lt.x = b.w_in ? b.w_in : b.d_sum;  // fill_task only checks x for NULL / aliasing
     int rc = fill_task(lt, 1, t);
     if (rc) return rc;
     t.e_saved = b.e_saved; t.d_sum = b.d_sum;
+    t.row_norm = const_cast<float *>(b.row_norm);
     if (b.w_in) {
       ggraphs[dst.n_tasks] = b.graph;
     } else {

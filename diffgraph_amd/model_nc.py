@@ -17,13 +17,64 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from ._lib import DG_ACC_REBUILD, DG_D, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE
+from ._lib import (DG_ACC_REBUILD, DG_BWD_NORM_FEED, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_NORM,
+                   DG_OUT_PRESCALE)
 from .diffusion import Denoise, GaussianDiffusion
 from .layers import UUGCNLayer
 
 DEFAULT_ARGS = SimpleNamespace(latdim=64, gcn_layer=3, uugcn_layer=3, dims="[64]", d_emb_size=8, norm=True, steps=200,
                                noise_scale=1e-5, noise_min=1e-4, noise_max=1e-3, sampling_steps=0,
                                batch=8)  # DiffGraph_NC/params.py:5-68
+
+
+def _launch_distinct(tasks, launch) -> None:
+    """Graphs that share a handle cannot share a launch (one hub slab per handle)."""
+    seen, batch = set(), []
+    for t in tasks:
+        if id(t.graph) in seen:
+            launch(batch)
+            seen, batch = set(), []
+        seen.add(id(t.graph))
+        batch.append(t)
+    launch(batch)
+
+
+class _PropagateFn(torch.autograd.Function):
+    """HGDM.propagate as one differentiable op of the layer-0 table (the output of
+    transform_layer).  The forward keeps each layer's normalised activation and its length
+    before normalisation; the backward walks the layers down with the transposed kernel:
+        G_L = dS,   dZ_l = LeakyReLU'(y_l) * normalize_backward(G_l; y_l),   G_{l-1} = dS + A^T dZ_l."""
+
+    @staticmethod
+    def forward(ctx, embed, model, he_adjs):
+        embed = embed.contiguous()
+        sums, saved, norms = model._propagate(he_adjs, embed, keep=True)
+        ctx.model, ctx.he_adjs, ctx.saved, ctx.norms = model, list(he_adjs), saved, norms
+        return tuple(sums)
+
+    @staticmethod
+    def backward(ctx, *d_sums):
+        model, graphs, saved, norms = ctx.model, ctx.he_adjs, ctx.saved, ctx.norms
+        slope, L = float(model.act.negative_slope), model.args.gcn_layer
+        ref = saved[0][0]
+        d_sum = [torch.zeros_like(ref) if d is None else d.contiguous() for d in d_sums]
+        w = [None] * len(graphs)
+        for l in range(L, 0, -1):
+            tasks = []
+            for g, graph in enumerate(graphs):
+                out = torch.empty_like(ref)
+                flags = DG_BWD_NORM_FEED | (DG_BWD_SAVED_PRESCALED if l < L else 0)
+                tasks.append(ops.BwdTask(graph, w[g], saved[g][l - 1], d_sum[g], out, flags, slope, norms[g][l - 1]))
+                w[g] = out
+            _launch_distinct(tasks, ops.gcn_layer_bwd_batched)
+        tasks = []
+        for g, graph in enumerate(graphs):
+            out = torch.empty_like(ref)
+            tasks.append(ops.BwdTask(graph, w[g], None, None, out, 0, slope))
+            w[g] = out
+        _launch_distinct(tasks, ops.gcn_layer_bwd_batched)
+        # every channel's layer sum starts from the same table (Model.py:48-50)
+        return ops.sum_tables(d_sum + w), None, None
 
 
 class HGDM(nn.Module):
@@ -49,37 +100,40 @@ class HGDM(nn.Module):
 
     def propagate(self, he_adjs, embed: torch.Tensor):
         """(sum over layers for he_adjs[0], [1], [2]) -- Model.py:52-71."""
+        if torch.is_grad_enabled() and embed.requires_grad:
+            return list(_PropagateFn.apply(embed, self, he_adjs))
+        return self._propagate(he_adjs, embed.detach().contiguous(), keep=False)[0]
+
+    def _propagate(self, he_adjs, embed: torch.Tensor, keep: bool):
         slope = float(self.act.negative_slope)
         L = self.args.gcn_layer
         sums = [torch.empty_like(embed) for _ in he_adjs]
         prev: List[Optional[torch.Tensor]] = [None] * len(he_adjs)
+        saved = [[] for _ in he_adjs]
+        norms = [[] for _ in he_adjs]
         for l in range(L):
             last = l == L - 1
             tasks = []
             for g, graph in enumerate(he_adjs):
-                e_out = None if last else torch.empty_like(embed)
-                flags = (DG_IN_PRESCALED if l > 0 else 0) | (0 if last else DG_OUT_PRESCALE | DG_OUT_NORM)
+                e_out = None if (last and not keep) else torch.empty_like(embed)
+                flags = (DG_IN_PRESCALED if l > 0 else 0) | DG_OUT_NORM | (0 if last else DG_OUT_PRESCALE)
                 if l == 0 and L >= 2:      # no running sum from the first layer; the second rebuilds it
                     acc_in = acc_out = None
                 elif l == 1:
                     acc_in, acc_out, flags = embed, sums[g], flags | DG_ACC_REBUILD
                 else:
                     acc_in, acc_out = (embed if l == 0 else sums[g]), sums[g]
-                tasks.append(ops.LayerTask(graph, embed if l == 0 else prev[g], e_out, acc_in, acc_out, flags, slope))
+                rn = torch.empty(embed.shape[0], dtype=torch.float32, device=embed.device) if keep else None
+                tasks.append(ops.LayerTask(graph, embed if l == 0 else prev[g], e_out, acc_in, acc_out, flags, slope,
+                                           row_norm_out=rn))
                 prev[g] = e_out
-            # graphs that share a handle cannot share a launch (one hub slab per handle)
-            seen, batch = set(), []
-            for t in tasks:
-                if id(t.graph) in seen:
-                    ops.gcn_layer_batched(batch)
-                    seen, batch = set(), []
-                seen.add(id(t.graph))
-                batch.append(t)
-            ops.gcn_layer_batched(batch)
-        return sums
+                saved[g].append(e_out)
+                norms[g].append(rn)
+            _launch_distinct(tasks, ops.gcn_layer_batched)
+        return sums, saved, norms
 
     def forward(self, he_adjs, feature_list, is_training=True):
-        embed = self.transform_layer(feature_list).detach().contiguous()
+        embed = self.transform_layer(feature_list)
         target, s1, s2 = self.propagate(he_adjs, embed)
         return s1, s2, target
 

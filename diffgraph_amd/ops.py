@@ -68,6 +68,12 @@ class LayerTask:
     slope: float = 0.5
     partial_out: Optional[torch.Tensor] = None   # sharded runs: raw neighbour sums of rows >= partial_from
     partial_from: int = 0
+    row_norm_out: Optional[torch.Tensor] = None  # [n] ||y|| before normalisation (for a normalised-feed backward)
+
+
+def _row_vector(v: torch.Tensor, name: str, n: int) -> None:
+    if v.dtype != torch.float32 or not v.is_cuda or not v.is_contiguous() or v.numel() != n:
+        raise DiffGraphHipError(f"{name}: expected a contiguous float32 GPU vector of {n} elements")
 
 
 def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
@@ -88,8 +94,11 @@ def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
                 _table(v, nm, n)
         if t.partial_out is not None:
             _table(t.partial_out, "partial_out", n - int(t.partial_from))
+        if t.row_norm_out is not None:
+            _row_vector(t.row_norm_out, "row_norm_out", n)
         arr[k] = _lib.LayerTask(t.graph.handle, t.x.data_ptr(), _ptr(t.e_out), _ptr(t.acc_in), _ptr(t.acc_out),
-                                int(t.flags), float(t.slope), _ptr(t.partial_out), int(t.partial_from))
+                                int(t.flags), float(t.slope), _ptr(t.partial_out), int(t.partial_from),
+                                _ptr(t.row_norm_out))
     rc = _lib.load().dg_gcn_layer_fwd(arr, n_tasks, DG_D, _lib.stream_ptr(dev))
     _lib.check(rc, "dg_gcn_layer_fwd")
 
@@ -120,6 +129,7 @@ class BwdTask:
     w_out: torch.Tensor
     flags: int = 0
     slope: float = 0.5
+    row_norm: Optional[torch.Tensor] = None   # [n] saved ||y||, read under DG_BWD_NORM_FEED
 
 
 def gcn_layer_bwd_batched(tasks: Sequence[BwdTask]) -> None:
@@ -137,8 +147,10 @@ def gcn_layer_bwd_batched(tasks: Sequence[BwdTask]) -> None:
             v = getattr(t, nm)
             if v is not None:
                 _table(v, nm, n)
+        if t.row_norm is not None:
+            _row_vector(t.row_norm, "row_norm", n)
         arr[k] = _lib.BwdTask(t.graph.handle, _ptr(t.w_in), _ptr(t.e_saved), _ptr(t.d_sum), t.w_out.data_ptr(),
-                              int(t.flags), float(t.slope))
+                              int(t.flags), float(t.slope), _ptr(t.row_norm))
     rc = _lib.load().dg_gcn_layer_bwd(arr, n_tasks, DG_D, _lib.stream_ptr(tasks[0].w_out.device))
     _lib.check(rc, "dg_gcn_layer_bwd")
 

@@ -114,6 +114,10 @@ typedef struct dg_layer_task {
    * partial_out == NULL disables this. */
   float *partial_out;
   int32_t partial_from;
+  /* [n] ||y[i]||_2 before normalisation, or NULL.  A backward pass through a layer whose
+   * NORMALISED activation fed the next layer (DG_OUT_NORM) needs it: e_out then no longer
+   * carries the length.  Written only when the row is normalised (acc_out or DG_OUT_NORM). */
+  float *row_norm_out;
 } dg_layer_task;
 
 int dg_gcn_layer_fwd(const dg_layer_task *tasks, int32_t n_tasks, int32_t d, void *stream);
@@ -142,7 +146,12 @@ int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_pa
  * DG_BWD_SAVED_PRESCALED says e_saved holds dinv_src[j]*E_l[j] (what a forward call with
  * DG_OUT_PRESCALE wrote); otherwise it holds E_l[j].
  * ---------------------------------------------------------------------------------- */
-enum { DG_BWD_SAVED_PRESCALED = 8 };
+enum { DG_BWD_SAVED_PRESCALED = 8, DG_BWD_NORM_FEED = 32 };
+/* DG_BWD_NORM_FEED: the layer sum AND the next layer were fed the normalised activation
+ * (DiffGraph_NC/Model.py:53-55: E_l = normalize(layer(E_{l-1}))).  Then e_saved holds the
+ * normalised activation (times dinv_src[j] under DG_BWD_SAVED_PRESCALED), row_norm the
+ * lengths ||y_l[j]|| the forward wrote through row_norm_out, and
+ *     dE[j] = normalize_backward(d_sum[j] + G[j]; y_l[j]). */
 
 typedef struct dg_bwd_task {
   dg_graph *graph;
@@ -152,6 +161,7 @@ typedef struct dg_bwd_task {
   float *w_out;
   int32_t flags;
   float slope;
+  const float *row_norm; /* [n], only read under DG_BWD_NORM_FEED */
 } dg_bwd_task;
 
 int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32_t d, void *stream);

@@ -2,6 +2,7 @@
 vectors.  Bar: fp32, |a-b| <= 1e-5 * max(|b|, row scale)  (tests.helpers.RTOL)."""
 import numpy as np
 import pytest
+import scipy.sparse as sp
 import torch
 
 import diffgraph_amd as dg
@@ -348,7 +349,7 @@ def test_rec_cal_loss_gradients_golden():
     m.args = SimpleNamespace(**{**vars(m.args), "batch": int(fx["cl_batch_div"][0]), "reg": float(fx["cl_batch_div"][1])})
     loss, bpr, reg, diff = m.cal_loss(dev(fx["cl_ancs"]), dev(fx["cl_poss"]), dev(fx["cl_negs"]), dev(fx["cl_ts_u"]),
                                       dev(fx["cl_noise_u"]), dev(fx["cl_ts_i"]), dev(fx["cl_noise_i"]))
-    np.testing.assert_allclose([float(loss), float(bpr), float(reg), float(diff)], fx["cl_losses"], rtol=1e-5)
+    np.testing.assert_allclose([float(v.detach()) for v in (loss, bpr, reg, diff)], fx["cl_losses"], rtol=1e-5)
     loss.backward()
     g = m.embedding_table.grad
     assert_rows_close(g[:nu], fx["cl_grad_user"], rtol=1e-4, what="grad user_emb")
@@ -360,6 +361,73 @@ def test_rec_cal_loss_gradients_golden():
             want = fx["cl_grad_" + pre + nm]
             scale = np.abs(want).max()
             np.testing.assert_allclose(gv.cpu().numpy(), want, rtol=0, atol=1e-4 * scale, err_msg="grad " + pre + nm)
+
+
+def test_nc_propagation_backward_matches_oracle_autograd():
+    """The normalised-feed variant (DiffGraph_NC/Model.py:52-71): d/d embed of sum_c <S_c, R_c> through three
+    layers, against torch autograd on the oracle; small graphs with an isolated node and a hub row."""
+    n = 300
+    rng = np.random.default_rng(12)
+    mats = []
+    for dens in (0.02, 0.05, 0.01):
+        a = sp.random(n, n, density=dens, random_state=rng, format="csr")
+        a = ((a + a.T) != 0).astype(np.float32).tolil()
+        a[7, :] = 0; a[:, 7] = 0            # isolated node
+        a[3, :] = 1; a[:, 3] = 1; a[7, 3] = 0; a[3, 7] = 0   # hub row
+        a = a.tocsr()
+        a.eliminate_zeros()
+        mats.append(a)
+    for kw in ({}, {"group_max": 2, "seg_len": 64}):
+        adjs = [dg.CSRGraph.from_scipy(m, **kw) for m in mats]
+        model = dg.nc.HGDM(20).eval()
+        gen = torch.Generator().manual_seed(8)
+        embed0 = torch.randn(n, 64, generator=gen) * 0.1
+        rs = [torch.randn(n, 64, generator=gen) for _ in range(3)]
+        embed = dev(embed0).requires_grad_(True)
+        sums = model.propagate(adjs, embed)               # (target, s1, s2)
+        sum((o * dev(r)).sum() for o, r in zip(sums, rs)).backward()
+        e_cpu = embed0.clone().requires_grad_(True)
+        eye, zero = torch.eye(64), torch.zeros(64)
+        edges = [(T(m.tocoo().row.astype(np.int64)), T(m.tocoo().col.astype(np.int64))) for m in mats]
+        s1, s2, tgt = O.nc_forward(edges, e_cpu, eye, zero, 3)
+        ((tgt * rs[0]).sum() + (s1 * rs[1]).sum() + (s2 * rs[2]).sum()).backward()
+        assert_rows_close(embed.grad, e_cpu.grad, rtol=2e-5, what=f"nc d embed {kw}")
+        for o, want in zip(sums, (tgt, s1, s2)):
+            assert_rows_close(o.detach(), want.detach(), what="nc forward under autograd")
+
+
+def test_nc_cal_loss_gradients_golden():
+    """One NC training step (DiffGraph_NC/main.py:378-386) on the as-named DBLP graphs reproduces the
+    REFERENCE's loss values and its gradients for every parameter."""
+    from tests.test_oracle_golden import _dblp_graphs
+    fx = load("nc_dblp.npz")
+    NA, apa, apcpa, aptpa, features = _dblp_graphs()
+    adjs = [dg.CSRGraph.from_scipy(m) for m in (apa, apcpa, aptpa)]
+    model = dg.nc.HGDM(features.shape[1]).eval()
+    dn = model.user_denoise_model
+    with torch.no_grad():
+        model.transform_layer.weight.copy_(dev(fx["w_t"])); model.transform_layer.bias.copy_(dev(fx["b_t"]))
+        model.dense.weight.copy_(dev(fx["w_dense"])); model.dense.bias.copy_(dev(fx["b_dense"]))
+        dn.emb_layer.weight.copy_(dev(fx["dn_w_emb"])); dn.emb_layer.bias.copy_(dev(fx["dn_b_emb"]))
+        dn.in_layers[0].weight.copy_(dev(fx["dn_w_in"])); dn.in_layers[0].bias.copy_(dev(fx["dn_b_in"]))
+        dn.out_layers[0].weight.copy_(dev(fx["dn_w_out"])); dn.out_layers[0].bias.copy_(dev(fx["dn_b_out"]))
+    onehot = torch.zeros(NA, 4)
+    onehot[torch.arange(NA), T(load("dblp_graph.npz")["labels"])] = 1.0
+    nll, diff = model.cal_loss(dev(fx["cl_ancs"]), dev(onehot), adjs, dev(features), dev(fx["tr_ts"]), dev(fx["tr_noise"]))
+    np.testing.assert_allclose([float(nll.detach()), float(diff.detach())], fx["tr_losses"], rtol=2e-5)
+    (nll + diff).backward()
+    got = {"transform_layer_weight": model.transform_layer.weight, "transform_layer_bias": model.transform_layer.bias,
+           "dense_weight": model.dense.weight, "dense_bias": model.dense.bias,
+           "user_denoise_model_emb_layer_weight": dn.emb_layer.weight, "user_denoise_model_emb_layer_bias": dn.emb_layer.bias,
+           "user_denoise_model_in_layers_0_weight": dn.in_layers[0].weight,
+           "user_denoise_model_in_layers_0_bias": dn.in_layers[0].bias,
+           "user_denoise_model_out_layers_0_weight": dn.out_layers[0].weight,
+           "user_denoise_model_out_layers_0_bias": dn.out_layers[0].bias}
+    for nm, prm in got.items():
+        want = fx["tr_grad_" + nm]
+        assert prm.grad is not None, nm
+        scale = np.abs(want).max()
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), want, rtol=0, atol=1e-4 * scale, err_msg="grad " + nm)
 
 
 # ------------------------------------------------------------------------------ (e) sharded

@@ -337,6 +337,19 @@ def gen_nc():
             nll, diff = model.cal_loss(ancs, onehot, adjs, features)
         fx["cl_ancs"], fx["cl_ts"], fx["cl_noise"] = np64(ancs), np64(rec.randint[0]), np64(rec.randn[0])
         fx["cl_losses"] = np.array([nll.item(), diff.item()], dtype=np.float64)
+    # one training step's gradients (main.py:378-386: loss = nll + diff_loss; backward) on the as-named
+    # graphs, dropout off, same recorded draws
+    adjs = [fg(apa), fg(apcpa), fg(aptpa)]
+    model.zero_grad()
+    with Recorder() as rec:
+        torch.manual_seed(31)
+        nll, diff = model.cal_loss(ancs, onehot, adjs, features)
+    (nll + diff).backward()
+    fx["tr_ts"], fx["tr_noise"] = np64(rec.randint[0]), np64(rec.randn[0])
+    fx["tr_losses"] = np.array([nll.item(), diff.item()], dtype=np.float64)
+    for nm, p in model.named_parameters():
+        if p.grad is not None:
+            fx["tr_grad_" + nm.replace(".", "_")] = np64(p.grad)
     np.savez_compressed(os.path.join(OUT, "nc_dblp.npz"), **fx)
     print("nc_dblp.npz:", len(fx), "arrays")
 
