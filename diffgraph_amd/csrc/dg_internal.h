@@ -14,6 +14,16 @@
 
 #define DG_EPI_BWD 0x100  // internal flag: backward epilogue
 #define DG_LDS_MAX_ROWS 383  // small-side rows kept in LDS (+1 zero row) = 96 KiB
+// window_rows_kernel: the small-side rows of such a graph are summed from windows of DG_WIN_ROWS
+// consecutive large-side rows staged in LDS (+1 zero row = 64 KiB).  Each of the 64 16-lane groups
+// of a workgroup owns up to DG_WIN_SLOTS "parts"; a part is a small-side row, or -- for rows that
+// meet many rows of every window -- that row restricted to a slice of the window.
+#define DG_WIN_ROWS 255
+#define DG_WIN_SLOTS 8
+#define DG_WIN_GROUPS 64
+#define DG_WIN_HDR 2           // dwords of per-slot entry-dword counts at the head of a (window, group) block
+#define DG_WIN_ENT_DWORDS 4096 // LDS room for one window's entry blocks (16 KiB)
+#define DG_WIN_MAX_BLOCKS 256
 
 // Records a printf-style message retrievable through dg_last_error(); returns `code`.
 int dg_fail(int code, const char *fmt, ...);
@@ -47,6 +57,17 @@ struct dg_csr {
   // [lds_split][16] words = 32 halfwords per row below the split: halfword 0 the degree, 1..31 the
   // first 31 neighbours as ids relative to the split (padding = n - lds_split, the zero row).
   uint32_t *lhead = nullptr;
+  // Rows [lds_split, n) (the small side) in the same graphs.  Their neighbour lists are regrouped by
+  // window of DG_WIN_ROWS large-side rows and by owning group: block (w, g) starts at dword
+  // woff[w * 64 + g] of wblocks and holds DG_WIN_HDR dwords = 8 byte counts (slot k: number of
+  // entry dwords), then the entry dwords slot after slot.  An entry dword is four one-byte row ids
+  // relative to the window (255 = the zero row, padding).  woff[w * 64] is a multiple of 4 and
+  // a window's blocks take at most DG_WIN_ENT_DWORDS dwords.
+  // witems[g * 8 + k] = part owned by group g in slot k, or -1; the parts of small-side row i are
+  // hub_desc[i].y .. hub_desc[i].z - 1 (n_parts in all).
+  uint32_t *wblocks = nullptr, *woff = nullptr;
+  int32_t *witems = nullptr;
+  int32_t n_windows = 0, n_parts = 0;
 };
 
 struct dg_graph {
@@ -86,6 +107,10 @@ struct dg_task_dev {
   int32_t lds_split;      // > 0: rows below it are summed by lds_rows_kernel
   int32_t lds_blk_begin, lds_blk_count;  // this task's workgroups in the lds_rows_kernel launch
   const float *dinv_gather;  // norm of a gathered node (by node id), for staging the LDS table
+  const uint32_t *wblocks, *woff;  // see dg_csr
+  const int32_t *witems;
+  int32_t n_windows, n_parts;
+  int32_t win_blk_begin, win_blk_count;  // this task's workgroups in the window_rows_kernel launch
   int32_t blk_begin;      // first block of this task in the main launch
   int32_t hub_blk_begin;  // first block of this task in the hub-row reduce launch
 };

@@ -35,8 +35,9 @@ constexpr int kHead = 13;  // neighbour ids carried in a group row's 16-word hea
 struct HostCsr {
   std::vector<int32_t> rowptr, colidx, row_order, head, wave_desc, hub_desc, seg_desc;
   std::vector<float> colscale, head_scale;
-  std::vector<uint32_t> lhead;
-  int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0, lds_split = 0;
+  std::vector<uint32_t> lhead, wblocks, woff;
+  std::vector<int32_t> witems;
+  int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0, lds_split = 0, n_windows = 0, n_parts = 0;
 };
 
 // CSR over `row` with ascending `col` inside each row: two stable counting sorts
@@ -83,6 +84,105 @@ int32_t bipartite_split(int32_t n, const HostCsr &c) {
   return s;
 }
 
+// The small-side rows [split, n) of an LDS-split graph, regrouped for window_rows_kernel (layout:
+// dg_csr::wblocks).  A row expected to meet many rows of every window is cut into parts by slice
+// of the window, so that no part is much longer than a group's fair share; parts are dealt to
+// the 64 groups longest first, each to the group with the least work so far.  Returns false when
+// the graph is too dense for the kernel's LDS entry buffer (the caller then drops the LDS split).
+bool build_windows(int32_t n, const std::vector<int32_t> &deg, HostCsr &c) {
+  const int32_t s = c.lds_split, m = n - s;
+  const int32_t nw = (s + DG_WIN_ROWS - 1) / DG_WIN_ROWS;
+  constexpr int G = DG_WIN_GROUPS, S = DG_WIN_SLOTS;
+  int64_t nnz_small = 0;
+  for (int32_t i = 0; i < m; ++i) nnz_small += deg[s + i];
+  const double per_window = (double)nnz_small / nw;  // entries of one window
+  if (per_window * 1.5 + G * (DG_WIN_HDR + S) * 4 > DG_WIN_ENT_DWORDS * 4) return false;
+  // parts per row
+  std::vector<int32_t> n_cut(m), first_part(m + 1, 0);
+  double share = std::max(per_window / G * 0.75, 8.0);
+  for (;;) {
+    int32_t total = 0;
+    for (int32_t i = 0; i < m; ++i) {
+      const double e = (double)deg[s + i] / nw;
+      n_cut[i] = std::min(16, std::max(1, (int32_t)std::ceil(e / share)));
+      total += n_cut[i];
+    }
+    if (total <= G * S) break;
+    share *= 1.25;
+  }
+  for (int32_t i = 0; i < m; ++i) first_part[i + 1] = first_part[i] + n_cut[i];
+  const int32_t n_parts = first_part[m];
+  c.n_parts = n_parts;
+  c.n_windows = nw;
+  std::vector<int32_t> part_row(n_parts), order(n_parts), group_of(n_parts), slot_of(n_parts);
+  std::vector<double> part_load(n_parts);
+  for (int32_t i = 0; i < m; ++i)
+    for (int32_t k = 0; k < n_cut[i]; ++k) {
+      part_row[first_part[i] + k] = i;
+      part_load[first_part[i] + k] = (double)deg[s + i] / n_cut[i];
+    }
+  for (int32_t v = 0; v < n_parts; ++v) order[v] = v;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return part_load[a] > part_load[b]; });
+  c.witems.assign(G * S, -1);
+  double load[G] = {0};
+  int32_t used[G] = {0};
+  for (int32_t v : order) {
+    int best = -1;
+    for (int g = 0; g < G; ++g)
+      if (used[g] < S && (best < 0 || load[g] < load[best])) best = g;
+    group_of[v] = best; slot_of[v] = used[best];
+    c.witems[best * S + used[best]] = v;
+    used[best]++;
+    load[best] += part_load[v] + 4.0 * nw;  // a slot costs a little even when empty
+  }
+  auto part_of = [&](int32_t i, int32_t local) { return first_part[i] + local * n_cut[i] / DG_WIN_ROWS; };
+  // entries of (window, group, slot)
+  std::vector<uint16_t> cnt((size_t)nw * G * S, 0);
+  for (int32_t i = 0; i < m; ++i)
+    for (int32_t p = c.rowptr[s + i]; p < c.rowptr[s + i + 1]; ++p) {
+      const int32_t u = c.colidx[p], w = u / DG_WIN_ROWS, v = part_of(i, u - w * DG_WIN_ROWS);
+      cnt[((size_t)w * G + group_of[v]) * S + slot_of[v]]++;
+    }
+  c.woff.assign((size_t)nw * G + 1, 0);
+  uint64_t total = 0;
+  for (int32_t w = 0; w < nw; ++w) {
+    total = (total + 3) & ~(uint64_t)3;
+    const uint64_t begin = total;
+    for (int g = 0; g < G; ++g) {
+      const size_t bv = (size_t)w * G + g;
+      c.woff[bv] = (uint32_t)total;
+      total += DG_WIN_HDR;
+      for (int k = 0; k < S; ++k) total += (cnt[bv * S + k] + 3) / 4;
+    }
+    if (total - begin > DG_WIN_ENT_DWORDS) return false;
+  }
+  c.woff[(size_t)nw * G] = (uint32_t)total;
+  c.wblocks.assign((size_t)total + 4, 0xffffffffu);  // every entry byte = 255, the zero row
+  std::vector<uint32_t> slot_byte((size_t)nw * G * S);  // first entry byte of each slot, within its block
+  for (size_t bv = 0; bv < (size_t)nw * G; ++bv) {
+    uint8_t *blk = reinterpret_cast<uint8_t *>(&c.wblocks[c.woff[bv]]);
+    uint32_t byte = DG_WIN_HDR * 4;
+    for (int k = 0; k < S; ++k) {
+      const uint32_t quads = (cnt[bv * S + k] + 3) / 4;  // <= 64
+      blk[k] = (uint8_t)quads;
+      slot_byte[bv * S + k] = byte;
+      byte += quads * 4;
+    }
+  }
+  std::fill(cnt.begin(), cnt.end(), 0);  // reused as the fill cursor
+  for (int32_t i = 0; i < m; ++i)
+    for (int32_t p = c.rowptr[s + i]; p < c.rowptr[s + i + 1]; ++p) {  // ascending ids within a slot
+      const int32_t u = c.colidx[p], w = u / DG_WIN_ROWS, local = u - w * DG_WIN_ROWS, v = part_of(i, local);
+      const size_t bv = (size_t)w * G + group_of[v], sv = bv * S + slot_of[v];
+      uint8_t *blk = reinterpret_cast<uint8_t *>(&c.wblocks[c.woff[bv]]);
+      blk[slot_byte[sv] + cnt[sv]++] = (uint8_t)local;
+    }
+  // hub_reduce_kernel adds the workgroups' partial sums of a row's parts: {row, first part, last part + 1, 0}
+  c.hub_desc.clear();
+  for (int32_t i = 0; i < m; ++i) c.hub_desc.insert(c.hub_desc.end(), {s + i, first_part[i], first_part[i + 1], 0});
+  return true;
+}
+
 // Rows ordered hub | wave | group, each class by falling degree (ties: rising row id), so
 // the longest work starts first and the four rows sharing a wavefront have like lengths.
 // Rows below c.lds_split (if set) are left to lds_rows_kernel and appear in no class.
@@ -90,13 +190,24 @@ void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c) {
   std::vector<int32_t> deg(n);
   for (int32_t i = 0; i < n; ++i) deg[i] = c.rowptr[i + 1] - c.rowptr[i];
   c.lds_split = 0;
+  c.lhead.clear(); c.wblocks.clear(); c.woff.clear(); c.witems.clear();
+  c.n_windows = c.n_parts = 0;
   {
     const int32_t s = bipartite_split(n, c);
     // worth it only when the large side is much larger than the LDS-resident side
-    if (s > 0 && n - s <= DG_LDS_MAX_ROWS && s >= 64 * (n - s)) c.lds_split = s;
+    if (s > 0 && n - s <= DG_LDS_MAX_ROWS && s >= 64 * (n - s)) {
+      c.lds_split = s;
+      if (!build_windows(n, deg, c)) {
+        c.lds_split = 0;
+        c.wblocks.clear(); c.woff.clear(); c.witems.clear(); c.hub_desc.clear();
+        c.n_windows = c.n_parts = 0;
+      }
+    }
   }
-  c.lhead.clear();
+  c.row_order.clear();
+  for (int32_t i = c.lds_split; i < n; ++i) c.row_order.push_back(i);
   if (c.lds_split > 0) {
+    // rows below the split: lds_rows_kernel; the others: window_rows_kernel, then hub_reduce_kernel
     const uint32_t pad = (uint32_t)(n - c.lds_split);  // the zero row of the LDS table
     c.lhead.assign((size_t)c.lds_split * 16, pad | (pad << 16));
     for (int32_t r = 0; r < c.lds_split; ++r) {
@@ -106,9 +217,10 @@ void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c) {
       for (int32_t k = 0; k < std::min(deg[r], 31); ++k) hw[k + 1] = (uint16_t)(c.colidx[c.rowptr[r] + k] - c.lds_split);
       for (int k = 0; k < 16; ++k) c.lhead[(size_t)r * 16 + k] = (uint32_t)hw[2 * k] | ((uint32_t)hw[2 * k + 1] << 16);
     }
+    c.n_hub = n - c.lds_split; c.n_wave = c.n_group = c.n_seg = 0;
+    c.seg_desc.clear(); c.wave_desc.clear(); c.head.clear(); c.head_scale.clear();
+    return;
   }
-  c.row_order.clear();
-  for (int32_t i = c.lds_split; i < n; ++i) c.row_order.push_back(i);
   std::stable_sort(c.row_order.begin(), c.row_order.end(),
                    [&](int32_t a, int32_t b) { return deg[a] > deg[b]; });
   n = (int32_t)c.row_order.size();  // rows scheduled in the three classes
@@ -173,6 +285,10 @@ hipError_t upload_csr(const HostCsr &h, dg_csr &d) {
   if ((e = upload(h.hub_desc, &d.hub_desc)) != hipSuccess) return e;
   if ((e = upload(h.seg_desc, &d.seg_desc)) != hipSuccess) return e;
   if ((e = upload(h.lhead, &d.lhead)) != hipSuccess) return e;
+  if ((e = upload(h.wblocks, &d.wblocks)) != hipSuccess) return e;
+  if ((e = upload(h.woff, &d.woff)) != hipSuccess) return e;
+  if ((e = upload(h.witems, &d.witems)) != hipSuccess) return e;
+  d.n_windows = h.n_windows; d.n_parts = h.n_parts;
   d.n_hub = h.n_hub; d.n_wave = h.n_wave; d.n_group = h.n_group; d.n_seg = h.n_seg;
   d.lds_split = h.lds_split;
   return hipSuccess;
@@ -182,6 +298,7 @@ void free_csr(dg_csr &d) {
   (void)hipFree(d.rowptr); (void)hipFree(d.colidx); (void)hipFree(d.colscale); (void)hipFree(d.row_order);
   (void)hipFree(d.head); (void)hipFree(d.head_scale); (void)hipFree(d.wave_desc); (void)hipFree(d.hub_desc);
   (void)hipFree(d.seg_desc); (void)hipFree(d.lhead);
+  (void)hipFree(d.wblocks); (void)hipFree(d.woff); (void)hipFree(d.witems);
   d = dg_csr();
 }
 
@@ -249,6 +366,8 @@ extern "C" int dg_graph_create_ex(int32_t n, int64_t nnz, const int32_t *src, co
   }
   if (e == hipSuccess) {
     size_t segs = (size_t)std::max(g->fwd.n_seg, g->bwd.n_seg);
+    // LDS-split graphs: one slab row per (part of a small-side row, workgroup of window_rows_kernel)
+    segs = std::max(segs, (size_t)std::max(g->fwd.n_parts, g->bwd.n_parts) * DG_WIN_MAX_BLOCKS);
     e = hipMalloc((void **)&g->slab, std::max<size_t>(segs, 1) * DG_D * sizeof(float));
   }
   if (e != hipSuccess) {

@@ -292,10 +292,16 @@ __global__ __launch_bounds__(256) void hub_reduce_kernel(const dg_task_batch bat
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l = lane & 15;
   const int h = (blockIdx.x - T.hub_blk_begin) * 4 + wave;
   if (h >= T.n_hub) return;
-  const int4 d = reinterpret_cast<const int4 *>(T.hub_desc)[h];
+  int4 d = reinterpret_cast<const int4 *>(T.hub_desc)[h];
+  int slab_rows = T.n_seg;
+  if (T.lds_split > 0) {  // partial sums of window_rows_kernel: win_blk_count slab rows per part of the row
+    d.z = d.z * T.win_blk_count;
+    d.y = d.y * T.win_blk_count;
+    slab_rows = T.n_parts * T.win_blk_count;
+  }
   const row_ctx rc = load_row_ctx(T, d.x, l);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  gather_rows<false, false>(table_rsrc(T.slab, T.n_seg), nullptr, nullptr, d.y + 16 * q, d.z, 64, l, acc);
+  gather_rows<false, false>(table_rsrc(T.slab, slab_rows), nullptr, nullptr, d.y + 16 * q, d.z, 64, l, acc);
   acc = add_groups(acc);
   if (q == 0) epilogue(T, d.x, rc, acc, l);
 }
@@ -426,6 +432,87 @@ __global__ __launch_bounds__(1024) void lds_rows_kernel(const dg_task_batch batc
   }
 }
 
+// Rows [lds_split, n) of the same graphs (the small side; each has neighbours all over the large
+// side).  A 1024-thread workgroup walks a contiguous run of windows of DG_WIN_ROWS large-side rows:
+// it copies the window's table rows (times their source norm unless already scaled) and the
+// window's entry blocks into LDS -- the next window's are requested before the current one is
+// summed -- and every 16-lane group adds, for each part it owns (dg_csr::wblocks), the window
+// rows on that part's list: one ds_read_b32 gives four list entries, four ds_read_b128 the rows.
+// The running sums of a group's (up to 8) parts stay in registers for the whole run and go to
+// the slab at the end, one slab row per (part, workgroup); hub_reduce_kernel adds a row's slab
+// rows in order.  All orders are fixed, so results are reproducible run to run.
+__global__ __launch_bounds__(1024) void window_rows_kernel(const dg_task_batch batch) {
+  extern __shared__ f32x4 tab[];  // [DG_WIN_ROWS + 1][16] rows (the last is zeros), then the entry blocks
+  uint32_t *ebuf = reinterpret_cast<uint32_t *>(tab + (DG_WIN_ROWS + 1) * 16);
+  int ti = 0;
+  for (int k = 0; k < batch.n_tasks; ++k)
+    if (batch.t[k].win_blk_count > 0 && (int)blockIdx.x >= batch.t[k].win_blk_begin) ti = k;
+  const dg_task_dev &T = batch.t[ti];
+  const int b = blockIdx.x - T.win_blk_begin, B = T.win_blk_count;
+  const int per = (T.n_windows + B - 1) / B;
+  const int w0 = b * per, w1 = min(T.n_windows, w0 + per);
+  const int split = T.lds_split;
+  const bool scale = !(T.flags & DG_IN_PRESCALED);
+  const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const f32x4 *t = tab + l;
+
+  f32x4 acc[DG_WIN_SLOTS];
+#pragma unroll
+  for (int k = 0; k < DG_WIN_SLOTS; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the next window, on its way while the current one is summed: its rows (4 float4 per thread) and
+  // their norms, 4 dwords of its entry blocks, and where this group's block starts among them
+  f32x4 pre[4];
+  float ps[4];
+  u32x4 pent;
+  int goff_next = 0;
+  auto fetch = [&](int w) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int i = threadIdx.x + 1024 * p, r = i >> 4, u = w * DG_WIN_ROWS + r;
+      pre[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ps[p] = 1.0f;
+      if (r < DG_WIN_ROWS && u < split) {
+        pre[p] = reinterpret_cast<const f32x4 *>(T.x)[(size_t)u * 16 + (i & 15)];
+        if (scale) ps[p] = T.dinv_gather[u];
+      }
+    }
+    const unsigned o0 = T.woff[w * DG_WIN_GROUPS], o1 = T.woff[(w + 1) * DG_WIN_GROUPS];
+    pent = u32x4{~0u, ~0u, ~0u, ~0u};
+    if (4 * threadIdx.x < o1 - o0) pent = reinterpret_cast<const u32x4 *>(T.wblocks + o0)[threadIdx.x];
+    goff_next = (int)(T.woff[w * DG_WIN_GROUPS + g] - o0);
+  };
+  if (w0 < w1) fetch(w0);
+  for (int w = w0; w < w1; ++w) {
+    __syncthreads();  // every group is done with the previous window
+#pragma unroll
+    for (int p = 0; p < 4; ++p) tab[threadIdx.x + 1024 * p] = pre[p] * ps[p];  // row 255 gets zeros
+    reinterpret_cast<u32x4 *>(ebuf)[threadIdx.x] = pent;
+    const uint32_t *e = ebuf + goff_next;
+    __syncthreads();
+    if (w + 1 < w1) fetch(w + 1);
+    const unsigned h0 = e[0], h1 = e[1];
+    unsigned dn = e[DG_WIN_HDR];  // the entry dword after the one being summed is always on its way
+    e += DG_WIN_HDR + 1;
+#pragma unroll
+    for (int k = 0; k < DG_WIN_SLOTS; ++k) {
+      const int c = ((k < 4 ? h0 : h1) >> (8 * (k & 3))) & 0xff;
+      for (int j = 0; j < c; ++j) {
+        const unsigned d = dn;
+        dn = *e++;  // at the end of the last block this reads the spare dword behind the buffer
+        const f32x4 v0 = t[(d & 0xffu) * 16], v1 = t[(d >> 8 & 0xffu) * 16];
+        const f32x4 v2 = t[(d >> 16 & 0xffu) * 16], v3 = t[(d >> 24) * 16];
+        acc[k] += v0; acc[k] += v1; acc[k] += v2; acc[k] += v3;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DG_WIN_SLOTS; ++k) {
+    const int part = T.witems[g * DG_WIN_SLOTS + k];
+    if (part >= 0) reinterpret_cast<f32x4 *>(T.slab)[((size_t)part * B + b) * 16 + l] = acc[k];
+  }
+}
+
 // Rows with nothing to gather (last layer of the backward pass): epilogue only, 16 lanes per row.
 __global__ __launch_bounds__(256) void rowwise_kernel(const dg_task_batch batch) {
   const dg_task_dev &T = find_task(batch, blockIdx.x, false);
@@ -462,6 +549,8 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   const dg_csr &c = transpose ? g->bwd : g->fwd;
   o.rowptr = c.rowptr; o.lhead = c.lhead; o.lds_split = c.lds_split; o.lds_blk_begin = 0; o.lds_blk_count = 0;
   o.dinv_gather = transpose ? g->dinv_dst : g->dinv_src;
+  o.wblocks = c.wblocks; o.woff = c.woff; o.witems = c.witems; o.n_windows = c.n_windows; o.n_parts = c.n_parts;
+  o.win_blk_begin = 0; o.win_blk_count = 0;
   o.colidx = c.colidx; o.head = c.head; o.wave_desc = c.wave_desc; o.hub_desc = c.hub_desc; o.seg_desc = c.seg_desc;
   o.colscale = c.colscale; o.head_scale = c.head_scale;
   o.dinv_row = transpose ? g->dinv_src : g->dinv_dst;
@@ -488,8 +577,8 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     blocks += ((t.n_seg + 3) >> 2) + ((t.n_wave + 3) >> 2) + ((t.n_group + 15) >> 4);
     hub_blocks += (t.n_hub + 3) >> 2;
   }
-  // workgroups of the LDS-table kernel: one per CU in total, shared out by the tasks' edge counts
-  int32_t lds_blocks = 0, lds_rows_max = 0;
+  // workgroups of the two LDS kernels: one per CU in total each, shared out by the tasks' work
+  int32_t lds_blocks = 0, lds_rows_max = 0, win_blocks = 0;
   {
     double w[DG_MAX_TASKS], wsum = 0;
     for (int k = 0; k < n_tasks; ++k) {
@@ -513,6 +602,22 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
         t.lds_blk_count = 0;
       }
     }
+    // small-side rows: a window costs its list entries plus staging 64 KB (worth ~1500 entries)
+    wsum = 0;
+    for (int k = 0; k < n_tasks; ++k) {
+      w[k] = batch.t[k].lds_split > 0 ? 0.5 * (double)graphs[k]->nnz + 1500.0 * batch.t[k].n_windows : 0.0;
+      wsum += w[k];
+    }
+    for (int k = 0; k < n_tasks; ++k) {
+      dg_task_dev &t = batch.t[k];
+      t.win_blk_begin = win_blocks;
+      t.win_blk_count = 0;
+      if (w[k] > 0) {
+        int32_t cnt = std::max(1, (int32_t)std::lround(cus * w[k] / wsum));
+        t.win_blk_count = std::min(std::min(cnt, t.n_windows), DG_WIN_MAX_BLOCKS);
+        win_blocks += t.win_blk_count;
+      }
+    }
   }
   for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
   if (lds_blocks > 0) {
@@ -524,6 +629,16 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
       lds_attr_set = true;
     }
     hipLaunchKernelGGL(lds_rows_kernel, dim3(lds_blocks), dim3(1024), lds_bytes, stream, batch);
+  }
+  if (win_blocks > 0) {
+    constexpr size_t win_lds = (DG_WIN_ROWS + 1) * DG_D * sizeof(float) + DG_WIN_ENT_DWORDS * 4 + 16;
+    static bool win_attr_set = false;
+    if (!win_attr_set) {
+      DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(window_rows_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
+      win_attr_set = true;
+    }
+    hipLaunchKernelGGL(window_rows_kernel, dim3(win_blocks), dim3(1024), win_lds, stream, batch);
   }
   if (blocks > 0) hipLaunchKernelGGL(gcn_layer_kernel, dim3(blocks), dim3(256), 0, stream, batch);
   if (hub_blocks > 0) hipLaunchKernelGGL(hub_reduce_kernel, dim3(hub_blocks), dim3(256), 0, stream, batch);
