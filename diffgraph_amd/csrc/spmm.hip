@@ -129,7 +129,7 @@ __device__ __forceinline__ float inv_norm(float ss) { return fminf(__builtin_amd
 // What the epilogue needs from memory; asked for before the neighbour rows so that it
 // arrives while they load.
 struct row_ctx {
-  float di, dsrc, rn;
+  float sc;    // lane 0 of the group: norm of the row node; lane 1: its norm as a source; lane 2: saved ||y||
   f32x4 a_in;  // forward: running layer sum (or e0 under DG_ACC_REBUILD); backward: saved activation
   f32x4 g_in;  // backward: gradient wrt the layer sum; forward under DG_ACC_REBUILD: the row's own x
 };
@@ -137,39 +137,38 @@ struct row_ctx {
 // Loads only -- no arithmetic on the loaded values here, so that the requests stay in flight
 // while the caller gathers the neighbour rows (or works on the previous row).
 __device__ __forceinline__ row_ctx load_row_ctx(const dg_task_dev &T, int row, int l) {
+  // which tables feed a_in / g_in / rn is a per-task (wavefront-uniform) choice: pick the pointers
+  // with scalar selects so that each value is ONE load from a loop-invariant base
+  const bool bwd = (T.flags & DG_EPI_BWD) != 0;
+  const float *a_src = bwd ? T.e_saved : (T.acc_out ? T.acc_in : nullptr);
+  const float *g_src = bwd ? (T.e_saved ? T.d_sum : nullptr) : ((T.flags & DG_ACC_REBUILD) ? T.x : nullptr);
+  const float *n_src = (bwd && (T.flags & DG_BWD_NORM_FEED)) ? T.row_norm : nullptr;
   row_ctx c;
   const size_t o = (size_t)row * (DG_D / 4) + l;
-  c.di = T.dinv_row[row];
-  c.dsrc = T.dinv_out[row];
+  const float *s_src = l == 0 ? T.dinv_row : (l == 1 ? T.dinv_out : (l == 2 ? n_src : nullptr));
+  c.sc = 0.f;
+  if (s_src) c.sc = s_src[row];  // one load instruction for the three per-row scalars
   c.a_in = f32x4{0.f, 0.f, 0.f, 0.f};
   c.g_in = c.a_in;
-  c.rn = 0.f;
-  if (T.flags & DG_EPI_BWD) {
-    if (T.flags & DG_BWD_NORM_FEED) c.rn = T.row_norm[row];
-    if (T.e_saved) {
-      c.a_in = reinterpret_cast<const f32x4 *>(T.e_saved)[o];
-      c.g_in = reinterpret_cast<const f32x4 *>(T.d_sum)[o];
-    }
-    return c;
-  }
-  if (T.acc_out) c.a_in = reinterpret_cast<const f32x4 *>(T.acc_in)[o];
-  if (T.flags & DG_ACC_REBUILD) c.g_in = reinterpret_cast<const f32x4 *>(T.x)[o];
+  if (a_src) c.a_in = reinterpret_cast<const f32x4 *>(a_src)[o];
+  if (g_src) c.g_in = reinterpret_cast<const f32x4 *>(g_src)[o];
   return c;
 }
 
 // Backward of LeakyReLU + F.normalize + layer sum for one row (see dg_gcn_layer_bwd).
 __device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, const row_ctx &rc, f32x4 acc, int l) {
   const size_t o = (size_t)row * (DG_D / 4) + l;
-  f32x4 G = acc * rc.di;
+  const float di = bcast16f<0>(rc.sc), dsrc = bcast16f<1>(rc.sc), rn = bcast16f<2>(rc.sc);
+  f32x4 G = acc * di;
   if (!T.e_saved) {
     reinterpret_cast<f32x4 *>(T.e_out)[o] = G;
     return;
   }
   const f32x4 e = rc.a_in, g = rc.g_in;
-  const float c = (T.flags & DG_BWD_SAVED_PRESCALED) ? rc.di : 1.0f;  // e = c * E_l
+  const float c = (T.flags & DG_BWD_SAVED_PRESCALED) ? di : 1.0f;  // e = c * E_l
   const float re = sqrtf(sum16(e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w));
   const bool feed = (T.flags & DG_BWD_NORM_FEED) != 0;  // e is the normalised activation; its length was saved
-  const float r = feed ? rc.rn : re / c;                // ||y_l||
+  const float r = feed ? rn : re / c;                // ||y_l||
   const f32x4 gt = feed ? g + G : g;                    // what reaches the normalisation from above
   f32x4 dE;
   if (r > 1e-12f) {  // y/||y||: d = (g - n (n.g)) / ||y||
@@ -187,7 +186,7 @@ __device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, cons
   dz.y = e.y > 0.f ? dE.y : dE.y * slope;
   dz.z = e.z > 0.f ? dE.z : dE.z * slope;
   dz.w = e.w > 0.f ? dE.w : dE.w * slope;
-  reinterpret_cast<f32x4 *>(T.e_out)[o] = dz * rc.dsrc;
+  reinterpret_cast<f32x4 *>(T.e_out)[o] = dz * dsrc;
 }
 
 // rst*norm, LeakyReLU, F.normalize, layer sum, next layer's input (Model.py:165-172,67-70).
@@ -198,7 +197,8 @@ __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const ro
     return;
   }
   const float slope = T.slope;
-  f32x4 y = acc * rc.di;
+  const float di = bcast16f<0>(rc.sc), dsrc = bcast16f<1>(rc.sc);
+  f32x4 y = acc * di;
   y.x = y.x > 0.f ? y.x : y.x * slope;
   y.y = y.y > 0.f ? y.y : y.y * slope;
   y.z = y.z > 0.f ? y.z : y.z * slope;
@@ -216,13 +216,13 @@ __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const ro
     if (T.flags & DG_ACC_REBUILD) {  // a = e0[i] + normalize(E_1[i]) from the stored p = dinv_src[i] * E_1[i]:
       const f32x4 p = rc.g_in;       // ||E_1|| = ||p|| / dsrc, so normalize(E_1) = p / max(||p||, 1e-12 * dsrc)
       const float ps = sum16(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w);
-      a += p * fminf(__builtin_amdgcn_rsqf(ps), 1e12f * __builtin_amdgcn_rcpf(rc.dsrc));
+      a += p * fminf(__builtin_amdgcn_rsqf(ps), 1e12f * __builtin_amdgcn_rcpf(dsrc));
     }
     reinterpret_cast<f32x4 *>(T.acc_out)[o] = a + yn;
   }
   if (T.e_out) {
     f32x4 e = (T.flags & DG_OUT_NORM) ? yn : y;
-    if (T.flags & DG_OUT_PRESCALE) e *= rc.dsrc;
+    if (T.flags & DG_OUT_PRESCALE) e *= dsrc;
     reinterpret_cast<f32x4 *>(T.e_out)[o] = e;
   }
 }
@@ -277,7 +277,7 @@ __device__ __forceinline__ const dg_task_dev &find_task(const dg_task_batch &bat
   int ti = 0;
   for (int k = 1; k < batch.n_tasks; ++k)
     if (b >= (hub ? batch.t[k].hub_blk_begin : batch.t[k].blk_begin)) ti = k;
-  return batch.t[ti];
+  return batch.t[__builtin_amdgcn_readfirstlane(ti)];
 }
 
 __global__ __launch_bounds__(256) void gcn_layer_kernel(const dg_task_batch batch) {
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(1024) void lds_rows_kernel(const dg_task_batch batc
   int ti = 0;
   for (int k = 0; k < batch.n_tasks; ++k)
     if (batch.t[k].lds_blk_count > 0 && (int)blockIdx.x >= batch.t[k].lds_blk_begin) ti = k;
-  const dg_task_dev &T = batch.t[ti];
+  const dg_task_dev &T = batch.t[__builtin_amdgcn_readfirstlane(ti)];  // scalar loads for every field
   const int split = T.lds_split, n_small = T.n - split;
   const bool scale = !(T.flags & DG_IN_PRESCALED);
   for (int i = threadIdx.x; i < (n_small + 1) * 16; i += blockDim.x) {
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(1024) void window_rows_kernel(const dg_task_batch b
   int ti = 0;
   for (int k = 0; k < batch.n_tasks; ++k)
     if (batch.t[k].win_blk_count > 0 && (int)blockIdx.x >= batch.t[k].win_blk_begin) ti = k;
-  const dg_task_dev &T = batch.t[ti];
+  const dg_task_dev &T = batch.t[__builtin_amdgcn_readfirstlane(ti)];
   const int b = blockIdx.x - T.win_blk_begin, B = T.win_blk_count;
   const int per = (T.n_windows + B - 1) / B;
   const int w0 = b * per, w1 = min(T.n_windows, w0 + per);
