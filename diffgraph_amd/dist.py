@@ -158,7 +158,7 @@ class ShardedRecPropagation:
 # --------------------------------------------------------------------------------------
 # bench.py leg for --gpus N > 1 (and for --workload industry at N = 1)
 # --------------------------------------------------------------------------------------
-def bench_sharded(args, rank: int, world: int, device) -> None:
+def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
     from . import data as dgdata
     import torch.distributed as dist
     workload = args.workload or "industry"
@@ -211,10 +211,29 @@ def bench_sharded(args, rank: int, world: int, device) -> None:
     layer_bytes_global = sum(4 * e + 1032 * n_total for e in nnz)
     per_rank_bytes = layer_bytes_global / world
     achieved = per_rank_bytes / (layer_ms * 1e-3) / 1e9
+    value = L * sum(nnz) * args.steps / elapsed
+
+    # The same workload on ONE GPU, measured by rank 0 in this very run (the other ranks wait), so that the
+    # scaling of this line can be read without a second run.
+    single = None
+    if world > 1 and rank == 0:
+        del prop, out
+        p1 = ShardedRecPropagation(inter, wl.n_user, wl.n_item, 0, 1, HipBackend(device))
+        e1 = torch.cat([torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)), ie]).to(device)
+        for _ in range(max(2, args.warmup // 2)):
+            p1.forward(e1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            p1.forward(e1)
+        torch.cuda.synchronize()
+        single = L * sum(nnz) * args.steps / (time.perf_counter() - t1)
+
+    res = None
     if rank == 0:
         res = {
             "metric": "SpMM edges/sec + achieved HBM GB/s per propagation layer",
-            "value": L * sum(nnz) * args.steps / elapsed, "unit": "edges/s",
+            "value": value, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -224,11 +243,14 @@ def bench_sharded(args, rank: int, world: int, device) -> None:
                                "item partial sums per layer",
                        "parallelism": f"user-row shards x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "one sharded propagation layer on rank 0 (gcn_layer_kernel + "
-                         "hub_reduce_kernel + exchange + partial_finalize_kernel)",
+                         "traffic": None, "kernel": "one sharded propagation layer on rank 0 (lds_rows_kernel + "
+                         "window_rows_kernel + hub_reduce_kernel + exchange + partial_finalize_kernel)",
                          "bytes_per_launch": per_rank_bytes, "ms_per_launch": layer_ms},
         }
-        print(json.dumps(res))
+        if single is not None:
+            res["config"]["same_workload_1gpu_edges_per_s"] = single
+            res["config"]["speedup_over_1gpu"] = value / single
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return res
