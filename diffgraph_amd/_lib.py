@@ -36,6 +36,12 @@ class BwdTask(C.Structure):
                 ("w_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float), ("row_norm", C.c_void_p)]
 
 
+class FinalizeTask(C.Structure):
+    _fields_ = [("graph", C.c_void_p), ("partials", C.c_void_p), ("n_parts", C.c_int32), ("part_stride_rows", C.c_int64),
+                ("row_begin", C.c_int32), ("n_rows", C.c_int32), ("x_prev", C.c_void_p), ("e_out", C.c_void_p),
+                ("acc_in", C.c_void_p), ("acc_out", C.c_void_p), ("flags", C.c_int32), ("slope", C.c_float)]
+
+
 class Denoiser(C.Structure):
     _fields_ = [("w_emb", C.c_void_p), ("b_emb", C.c_void_p), ("w_in", C.c_void_p), ("b_in", C.c_void_p),
                 ("w_out", C.c_void_p), ("b_out", C.c_void_p), ("freqs_host", C.POINTER(C.c_float)),
@@ -65,6 +71,7 @@ SIGNATURES = {
     "dg_gcn_layer_fwd": (C.c_int, [C.POINTER(LayerTask), C.c_int32, C.c_int32, C.c_void_p]),
     "dg_gcn_partial_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "dg_gcn_partial_finalize_batched": (C.c_int, [C.POINTER(FinalizeTask), C.c_int32, C.c_int32, C.c_void_p]),
     "dg_gcn_layer_bwd": (C.c_int, [C.POINTER(BwdTask), C.c_int32, C.c_int32, C.c_void_p]),
     "dg_sum_tables": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dg_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,

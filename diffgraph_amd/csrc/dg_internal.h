@@ -111,6 +111,9 @@ struct dg_task_dev {
   const int32_t *witems;
   int32_t n_windows, n_parts;
   int32_t win_blk_begin, win_blk_count;  // this task's workgroups in the window_rows_kernel launch
+  const float *fin_partials;  // dg_gcn_partial_finalize: partial sums [n_parts][stride rows][64] ...
+  int64_t fin_stride;         // ... rows between parts
+  int32_t fin_parts, fin_row_begin, fin_rows;  // ... for rows [fin_row_begin, fin_row_begin + fin_rows)
   int32_t blk_begin;      // first block of this task in the main launch
   int32_t hub_blk_begin;  // first block of this task in the hub-row reduce launch
 };

@@ -286,39 +286,52 @@ __global__ __launch_bounds__(256) void gcn_layer_kernel(const dg_task_batch batc
   else layer_block<true>(T, blockIdx.x - T.blk_begin);
 }
 
-// Hub rows: one wavefront per row adds the row's slab rows in order, then the epilogue.
+// Hub rows: one wavefront per row adds the row's slab rows in order, then the epilogue.  Rows of
+// LDS-split tasks have thousands of slab rows (parts x workgroups of window_rows_kernel): there a
+// whole workgroup takes one row, each wavefront a quarter of the slab rows, and wavefront 0 adds
+// the four sums in order.
 __global__ __launch_bounds__(256) void hub_reduce_kernel(const dg_task_batch batch) {
+  __shared__ f32x4 red[4][16];
   const dg_task_dev &T = find_task(batch, blockIdx.x, true);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l = lane & 15;
+  if (T.lds_split > 0) {
+    const int h = blockIdx.x - T.hub_blk_begin;  // < n_hub by construction of the grid
+    const int4 d = reinterpret_cast<const int4 *>(T.hub_desc)[h];
+    const int first = d.y * T.win_blk_count, total = (d.z - d.y) * T.win_blk_count;
+    const int per = ((total + 255) >> 8) << 6;  // a quarter, rounded up to whole 64-row steps
+    const int begin = first + wave * per, end = min(first + total, begin + per);
+    const row_ctx rc = load_row_ctx(T, d.x, l);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    gather_rows<false, false>(table_rsrc(T.slab, T.n_parts * T.win_blk_count), nullptr, nullptr, begin + 16 * q, end, 64,
+                              l, acc);
+    acc = add_groups(acc);
+    if (q == 0) red[wave][l] = acc;
+    __syncthreads();
+    if (wave == 0 && q == 0) epilogue(T, d.x, rc, ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l], l);
+    return;
+  }
   const int h = (blockIdx.x - T.hub_blk_begin) * 4 + wave;
   if (h >= T.n_hub) return;
-  int4 d = reinterpret_cast<const int4 *>(T.hub_desc)[h];
-  int slab_rows = T.n_seg;
-  if (T.lds_split > 0) {  // partial sums of window_rows_kernel: win_blk_count slab rows per part of the row
-    d.z = d.z * T.win_blk_count;
-    d.y = d.y * T.win_blk_count;
-    slab_rows = T.n_parts * T.win_blk_count;
-  }
+  const int4 d = reinterpret_cast<const int4 *>(T.hub_desc)[h];
   const row_ctx rc = load_row_ctx(T, d.x, l);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  gather_rows<false, false>(table_rsrc(T.slab, slab_rows), nullptr, nullptr, d.y + 16 * q, d.z, 64, l, acc);
+  gather_rows<false, false>(table_rsrc(T.slab, T.n_seg), nullptr, nullptr, d.y + 16 * q, d.z, 64, l, acc);
   acc = add_groups(acc);
   if (q == 0) epilogue(T, d.x, rc, acc, l);
 }
 
 // Row-sharded layer, second half: sum the ranks' partial neighbour sums of a row in rank
-// order, then the usual epilogue.  16 lanes per row.
-__global__ __launch_bounds__(256) void partial_finalize_kernel(const dg_task_dev T, const float *__restrict__ partials,
-                                                               int n_parts, int64_t part_stride, int row_begin,
-                                                               int n_rows) {
+// order, then the usual epilogue.  16 lanes per row; all graphs of the layer in one launch.
+__global__ __launch_bounds__(256) void partial_finalize_kernel(const dg_task_batch batch) {
+  const dg_task_dev &T = find_task(batch, blockIdx.x, false);
   const int l = threadIdx.x & 15;
-  const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (r >= n_rows) return;
-  const int row = row_begin + r;
+  const int r = (blockIdx.x - T.blk_begin) * 16 + (threadIdx.x >> 4);
+  if (r >= T.fin_rows) return;
+  const int row = T.fin_row_begin + r;
   const row_ctx rc = load_row_ctx(T, row, l);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int p = 0; p < n_parts; ++p)
-    acc += reinterpret_cast<const f32x4 *>(partials)[((size_t)p * part_stride + r) * (DG_D / 4) + l];
+  for (int p = 0; p < T.fin_parts; ++p)
+    acc += reinterpret_cast<const f32x4 *>(T.fin_partials)[((size_t)p * T.fin_stride + r) * (DG_D / 4) + l];
   epilogue(T, row, rc, acc, l);
 }
 
@@ -559,6 +572,7 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   o.n = g->n; o.n_hub = c.n_hub; o.n_wave = c.n_wave; o.n_group = c.n_group; o.n_seg = c.n_seg;
   o.flags = in.flags; o.slope = in.slope;
   o.e_saved = nullptr; o.d_sum = nullptr;
+  o.fin_partials = nullptr; o.fin_stride = 0; o.fin_parts = o.fin_row_begin = o.fin_rows = 0;
   o.partial_out = in.partial_out; o.partial_from = in.partial_from;
   o.row_norm = in.row_norm_out;
   return 0;
@@ -575,7 +589,7 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     t.blk_begin = blocks;
     t.hub_blk_begin = hub_blocks;
     blocks += ((t.n_seg + 3) >> 2) + ((t.n_wave + 3) >> 2) + ((t.n_group + 15) >> 4);
-    hub_blocks += (t.n_hub + 3) >> 2;
+    hub_blocks += t.lds_split > 0 ? t.n_hub : (t.n_hub + 3) >> 2;
   }
   // workgroups of the two LDS kernels: one per CU in total each, shared out by the tasks' work
   int32_t lds_blocks = 0, lds_rows_max = 0, win_blocks = 0;
@@ -677,27 +691,51 @@ extern "C" int dg_spmm_norm_act_fwd(dg_graph *g, const float *x, float *y, int32
   return launch_layer(&t, 1, transpose, (hipStream_t)stream);
 }
 
-extern "C" int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_parts,
-                                       int64_t part_stride_rows, int32_t row_begin, int32_t n_rows, const float *x_prev, float *e_out, const float *acc_in,
-                                       float *acc_out, int32_t flags, float slope, int32_t d, void *stream) {
+extern "C" int dg_gcn_partial_finalize_batched(const dg_finalize_task *tasks, int32_t n_tasks, int32_t d, void *stream) {
   if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_gcn_partial_finalize: embedding width %d unsupported (built for %d)", d, DG_D);
-  if (!graph || !partials || n_parts <= 0) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: NULL argument");
-  if (part_stride_rows < n_rows) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: part stride smaller than a part");
-  if (row_begin < 0 || n_rows < 0 || (int64_t)row_begin + n_rows > graph->n)
-    return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: rows [%d,%d) outside the graph's %d nodes", row_begin,
-                   row_begin + n_rows, graph->n);
-  if (n_rows == 0) return 0;
-  if ((flags & DG_ACC_REBUILD) && !x_prev) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: DG_ACC_REBUILD needs x_prev");
-  dg_layer_task lt;
-  lt.graph = graph; lt.x = x_prev ? x_prev : partials; lt.e_out = e_out; lt.acc_in = acc_in; lt.acc_out = acc_out;
-  lt.flags = flags; lt.slope = slope; lt.partial_out = nullptr; lt.partial_from = 0; lt.row_norm_out = nullptr;
-  dg_task_dev t;
-  int rc = fill_task(lt, 0, t);
-  if (rc) return rc;
-  hipLaunchKernelGGL(partial_finalize_kernel, dim3((n_rows + 15) >> 4), dim3(256), 0, (hipStream_t)stream, t, partials,
-                     n_parts, part_stride_rows, row_begin, n_rows);
+  if (!tasks || n_tasks <= 0 || n_tasks > DG_MAX_TASKS)
+    return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: n_tasks must be in [1,%d] (got %d)", DG_MAX_TASKS, n_tasks);
+  dg_task_batch batch;
+  batch.n_tasks = 0;
+  int32_t blocks = 0;
+  for (int k = 0; k < n_tasks; ++k) {
+    const dg_finalize_task &f = tasks[k];
+    if (!f.graph || !f.partials || f.n_parts <= 0) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: task %d: NULL argument", k);
+    if (f.part_stride_rows < f.n_rows) return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: task %d: part stride smaller than a part", k);
+    if (f.row_begin < 0 || f.n_rows < 0 || (int64_t)f.row_begin + f.n_rows > f.graph->n)
+      return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: task %d: rows [%d,%d) outside the graph's %d nodes", k, f.row_begin,
+                     f.row_begin + f.n_rows, f.graph->n);
+    if ((f.flags & DG_ACC_REBUILD) && !f.x_prev)
+      return dg_fail(DG_ERR_ARG, "dg_gcn_partial_finalize: task %d: DG_ACC_REBUILD needs x_prev", k);
+    if (f.n_rows == 0) continue;
+    dg_layer_task lt;
+    lt.graph = f.graph; lt.x = f.x_prev ? f.x_prev : f.partials; lt.e_out = f.e_out; lt.acc_in = f.acc_in; lt.acc_out = f.acc_out;
+    lt.flags = f.flags; lt.slope = f.slope; lt.partial_out = nullptr; lt.partial_from = 0; lt.row_norm_out = nullptr;
+    dg_task_dev &t = batch.t[batch.n_tasks];
+    int rc = fill_task(lt, 0, t);
+    if (rc) return rc;
+    t.fin_partials = f.partials; t.fin_parts = f.n_parts; t.fin_stride = f.part_stride_rows;
+    t.fin_row_begin = f.row_begin; t.fin_rows = f.n_rows;
+    t.blk_begin = blocks;
+    blocks += (f.n_rows + 15) >> 4;
+    batch.n_tasks++;
+  }
+  if (blocks == 0) return 0;
+  for (int k = batch.n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
+  hipLaunchKernelGGL(partial_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, batch);
   DG_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_parts,
+                                       int64_t part_stride_rows, int32_t row_begin, int32_t n_rows, const float *x_prev,
+                                       float *e_out, const float *acc_in, float *acc_out, int32_t flags, float slope,
+                                       int32_t d, void *stream) {
+  dg_finalize_task f;
+  f.graph = graph; f.partials = partials; f.n_parts = n_parts; f.part_stride_rows = part_stride_rows;
+  f.row_begin = row_begin; f.n_rows = n_rows; f.x_prev = x_prev; f.e_out = e_out; f.acc_in = acc_in; f.acc_out = acc_out;
+  f.flags = flags; f.slope = slope;
+  return dg_gcn_partial_finalize_batched(&f, 1, d, stream);
 }
 
 extern "C" int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32_t d, void *stream) {

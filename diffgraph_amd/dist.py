@@ -78,9 +78,9 @@ class HipBackend:
         from . import ops
         ops.gcn_layer_batched([ops.LayerTask(**t) for t in tasks])
 
-    def finalize(self, graph, partials, row_begin, e_out, acc_in, acc_out, flags, slope, x=None) -> None:
+    def finalize(self, tasks) -> None:
         from . import ops
-        ops.gcn_partial_finalize(graph, partials, row_begin, e_out, acc_in, acc_out, flags, slope, x=x)
+        ops.gcn_partial_finalize_batched([ops.FinalizeTask(**t) for t in tasks])
 
     def sum_tables(self, tables):
         from . import ops
@@ -146,9 +146,9 @@ class ShardedRecPropagation:
                 self.hook("begin", l)
             be.layer(tasks)
             gathered = self._exchange(partials)
-            for g in range(G):
-                be.finalize(self.graphs[g], gathered[:, g], self.n_loc, outs[g], tasks[g]["acc_in"], tasks[g]["acc_out"],
-                            flags, self.slope, x=tasks[g]["x"])
+            be.finalize([dict(graph=self.graphs[g], partials=gathered[:, g], row_begin=self.n_loc, e_out=outs[g],
+                              acc_in=tasks[g]["acc_in"], acc_out=tasks[g]["acc_out"], flags=flags, slope=self.slope,
+                              x=tasks[g]["x"]) for g in range(G)])
             if self.hook:
                 self.hook("end", l)
             prev = outs

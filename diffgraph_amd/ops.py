@@ -103,21 +103,47 @@ def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
     _lib.check(rc, "dg_gcn_layer_fwd")
 
 
+@dataclass
+class FinalizeTask:
+    graph: CSRGraph
+    partials: torch.Tensor          # [n_parts, n_rows, 64]; the parts may be strided (a slice of a gathered buffer)
+    row_begin: int
+    e_out: Optional[torch.Tensor]
+    acc_in: Optional[torch.Tensor]
+    acc_out: Optional[torch.Tensor]
+    flags: int = 0
+    slope: float = 0.5
+    x: Optional[torch.Tensor] = None  # the layer's gather source (read under DG_ACC_REBUILD)
+
+
+def gcn_partial_finalize_batched(tasks: Sequence[FinalizeTask]) -> None:
+    """Second half of a row-sharded layer for all its graphs in one launch (see dg_gcn_partial_finalize)."""
+    if not tasks:
+        return
+    n_tasks = len(tasks)
+    if n_tasks > _lib.DG_MAX_TASKS:
+        raise DiffGraphHipError(f"at most {_lib.DG_MAX_TASKS} graphs per batched launch")
+    arr = (_lib.FinalizeTask * n_tasks)()
+    for k, t in enumerate(tasks):
+        p = t.partials
+        if p.dim() != 3 or p.shape[2] != DG_D or p.dtype != torch.float32 or not p.is_cuda \
+                or p.stride(2) != 1 or p.stride(1) != DG_D or p.stride(0) % DG_D != 0:
+            raise DiffGraphHipError("partials: expected a float32 GPU tensor [n_parts, n_rows, 64] with contiguous rows")
+        n = t.graph.num_nodes()
+        for nm, v in (("e_out", t.e_out), ("acc_in", t.acc_in), ("acc_out", t.acc_out), ("x", t.x)):
+            if v is not None:
+                _table(v, nm, n)
+        arr[k] = _lib.FinalizeTask(t.graph.handle, p.data_ptr(), p.shape[0], p.stride(0) // DG_D, int(t.row_begin),
+                                   p.shape[1], _ptr(t.x), _ptr(t.e_out), _ptr(t.acc_in), _ptr(t.acc_out), int(t.flags),
+                                   float(t.slope))
+    rc = _lib.load().dg_gcn_partial_finalize_batched(arr, n_tasks, DG_D, _lib.stream_ptr(tasks[0].partials.device))
+    _lib.check(rc, "dg_gcn_partial_finalize_batched")
+
+
 def gcn_partial_finalize(graph: CSRGraph, partials: torch.Tensor, row_begin: int, e_out, acc_in, acc_out, flags: int,
                          slope: float, x: Optional[torch.Tensor] = None) -> None:
-    """partials: [n_parts, n_rows, 64] partial neighbour sums of rows [row_begin, row_begin+n_rows); the parts may
-    be strided (a slice [:, g] of a gathered [n_parts, graphs, n_rows, 64] buffer)."""
-    if partials.dim() != 3 or partials.shape[2] != DG_D or partials.dtype != torch.float32 or not partials.is_cuda \
-            or partials.stride(2) != 1 or partials.stride(1) != DG_D or partials.stride(0) % DG_D != 0:
-        raise DiffGraphHipError("partials: expected a float32 GPU tensor [n_parts, n_rows, 64] with contiguous rows")
-    n = graph.num_nodes()
-    for nm, v in (("e_out", e_out), ("acc_in", acc_in), ("acc_out", acc_out), ("x", x)):
-        if v is not None:
-            _table(v, nm, n)
-    rc = _lib.load().dg_gcn_partial_finalize(graph.handle, partials.data_ptr(), partials.shape[0],
-                                             partials.stride(0) // DG_D, int(row_begin), partials.shape[1], _ptr(x), _ptr(e_out), _ptr(acc_in), _ptr(acc_out), int(flags),
-                                             float(slope), DG_D, _lib.stream_ptr(partials.device))
-    _lib.check(rc, "dg_gcn_partial_finalize")
+    """One graph's share of gcn_partial_finalize_batched."""
+    gcn_partial_finalize_batched([FinalizeTask(graph, partials, row_begin, e_out, acc_in, acc_out, flags, slope, x)])
 
 
 @dataclass

@@ -134,6 +134,23 @@ int dg_gcn_partial_finalize(dg_graph *graph, const float *partials, int32_t n_pa
                             int32_t d, void *stream);   /* x_prev: the layer's gather source, read only
                                                            under DG_ACC_REBUILD (may be NULL otherwise) */
 
+/* The same for several graphs in ONE launch (the graphs of a layer, as dg_gcn_layer_fwd). */
+typedef struct dg_finalize_task {
+  dg_graph *graph;
+  const float *partials;
+  int32_t n_parts;
+  int64_t part_stride_rows;
+  int32_t row_begin, n_rows;
+  const float *x_prev;
+  float *e_out;
+  const float *acc_in;
+  float *acc_out;
+  int32_t flags;
+  float slope;
+} dg_finalize_task;
+
+int dg_gcn_partial_finalize_batched(const dg_finalize_task *tasks, int32_t n_tasks, int32_t d, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * a11: backward of one fused propagation layer, batched over graphs.  Replaces what
  * autograd records for DGLLayer.forward + F.normalize + the layer sum

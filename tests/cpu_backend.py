@@ -42,12 +42,14 @@ class CpuBackend:
             rows = slice(0, pf)
             self._epilogue(g, rows, s[rows], t["e_out"], t["acc_in"], t["acc_out"], t["flags"], t["slope"], x)
 
-    def finalize(self, g, partials, row_begin, e_out, acc_in, acc_out, flags, slope, x=None):
-        s = torch.zeros_like(partials[0])
-        for p in range(partials.shape[0]):
-            s = s + partials[p]
-        rows = slice(row_begin, row_begin + partials.shape[1])
-        self._epilogue(g, rows, s, e_out, acc_in, acc_out, flags, slope, x)
+    def finalize(self, tasks):
+        for t in tasks:
+            partials = t["partials"]
+            s = torch.zeros_like(partials[0])
+            for p in range(partials.shape[0]):
+                s = s + partials[p]
+            rows = slice(t["row_begin"], t["row_begin"] + partials.shape[1])
+            self._epilogue(t["graph"], rows, s, t["e_out"], t["acc_in"], t["acc_out"], t["flags"], t["slope"], t["x"])
 
     def sum_tables(self, tables):
         out = tables[0]
