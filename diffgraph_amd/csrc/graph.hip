@@ -186,14 +186,14 @@ bool build_windows(int32_t n, const std::vector<int32_t> &deg, HostCsr &c) {
 // Rows ordered hub | wave | group, each class by falling degree (ties: rising row id), so
 // the longest work starts first and the four rows sharing a wavefront have like lengths.
 // Rows below c.lds_split (if set) are left to lds_rows_kernel and appear in no class.
-void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c) {
+void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c, const std::vector<char> *owned = nullptr) {
   std::vector<int32_t> deg(n);
   for (int32_t i = 0; i < n; ++i) deg[i] = c.rowptr[i + 1] - c.rowptr[i];
   c.lds_split = 0;
   c.lhead.clear(); c.wblocks.clear(); c.woff.clear(); c.witems.clear();
   c.n_windows = c.n_parts = 0;
   {
-    const int32_t s = bipartite_split(n, c);
+    const int32_t s = owned ? 0 : bipartite_split(n, c);  // row-block shards take the general path
     // worth it only when the large side is much larger than the LDS-resident side
     if (s > 0 && n - s <= DG_LDS_MAX_ROWS && s >= 64 * (n - s)) {
       c.lds_split = s;
@@ -205,7 +205,8 @@ void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c) {
     }
   }
   c.row_order.clear();
-  for (int32_t i = c.lds_split; i < n; ++i) c.row_order.push_back(i);
+  for (int32_t i = c.lds_split; i < n; ++i)
+    if (!owned || (*owned)[i]) c.row_order.push_back(i);
   if (c.lds_split > 0) {
     // rows below the split: lds_rows_kernel; the others: window_rows_kernel, then hub_reduce_kernel
     const uint32_t pad = (uint32_t)(n - c.lds_split);  // the zero row of the LDS table
@@ -346,7 +347,16 @@ extern "C" int dg_graph_create_ex(int32_t n, int64_t nnz, const int32_t *src, co
   }
   f.colscale.resize((size_t)nnz);
   for (int64_t p = 0; p < nnz; ++p) f.colscale[(size_t)p] = dsrc[f.colidx[(size_t)p]];  // gathered node = a source
-  build_schedule(n, group_max, seg_len, f);
+  std::vector<char> owned;
+  bool all_owned = true;
+  if (in_deg_host) {
+    owned.resize(n);
+    for (int32_t i = 0; i < n; ++i) {
+      owned[i] = in_deg_host[i] >= 0;
+      all_owned = all_owned && owned[i];
+    }
+  }
+  build_schedule(n, group_max, seg_len, f, all_owned ? nullptr : &owned);
   if (!symmetric) {
     b.colscale.resize((size_t)nnz);
     for (int64_t p = 0; p < nnz; ++p) b.colscale[(size_t)p] = ddst[b.colidx[(size_t)p]];
@@ -400,7 +410,7 @@ extern "C" int dg_graph_export(const dg_graph *g, int which, void *dst, size_t b
     case 1: src = g->fwd.colidx; need = (size_t)g->nnz * 4; break;
     case 2: src = g->dinv_src; need = (size_t)g->n * 4; break;
     case 3: src = g->dinv_dst; need = (size_t)g->n * 4; break;
-    case 4: src = g->fwd.row_order; need = (size_t)(g->n - g->fwd.lds_split) * 4; break;
+    case 4: src = g->fwd.row_order; need = (size_t)(g->fwd.n_hub + g->fwd.n_wave + g->fwd.n_group) * 4; break;
     case 5:
       if (bytes < sizeof(counts)) return dg_fail(DG_ERR_SIZE, "dg_graph_export: buffer too small");
       memcpy(dst, counts, sizeof(counts));

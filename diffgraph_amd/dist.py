@@ -48,6 +48,7 @@ class LocalGraph:
     dst: np.ndarray
     degrees: np.ndarray     # GLOBAL degrees of the local nodes (symmetric graph: in == out)
     n_edges_global: int     # directed edges of the whole graph
+    in_degrees: Optional[np.ndarray] = None   # if set: in-degrees, with -1 for rows this rank does not own
 
 
 def shard_bipartite(u: np.ndarray, i: np.ndarray, n_user: int, n_item: int, u0: int, u1: int) -> LocalGraph:
@@ -69,7 +70,8 @@ class HipBackend:
 
     def make_graph(self, lg: LocalGraph, n_nodes: int):
         from .graph import CSRGraph
-        return CSRGraph(lg.src, lg.dst, n_nodes, out_degrees=lg.degrees, in_degrees=lg.degrees)
+        return CSRGraph(lg.src, lg.dst, n_nodes, out_degrees=lg.degrees,
+                        in_degrees=lg.degrees if lg.in_degrees is None else lg.in_degrees)
 
     def empty(self, rows: int) -> torch.Tensor:
         return torch.empty((rows, DG_D), dtype=torch.float32, device=self.device)
@@ -85,6 +87,92 @@ class HipBackend:
     def sum_tables(self, tables):
         from . import ops
         return ops.sum_tables(tables)
+
+
+def all_gather_stack(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """[...] on every rank -> [world, ...] in rank order (one RCCL all-gather on GPU tensors)."""
+    if world == 1:
+        return t.unsqueeze(0)
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # single-GPU rehearsal of the multi-process path: gloo moves host memory
+        host = t.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return torch.stack(parts, dim=0).to(t.device)
+    if t.is_cuda:
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)   # no re-packing
+        return out
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    return torch.stack(parts, dim=0)
+
+
+class RowBlockPropagation:
+    """The general partition: contiguous, equal blocks of the rows of A_hat (and of every table) per rank,
+    ONE all-gather of each graph's activation table per layer.  Works for any symmetric graph set; it is
+    what a Tmall-shaped graph would use (neither side is small).  A rank holds the edges that end in its
+    block, full-height tables (only its rows of the outputs are valid) and the whole graph's degrees.
+    Same layer semantics as HGDM.forward (DiffGraph-Rec/Model.py:53-92)."""
+
+    def __init__(self, graphs: Sequence[Tuple[np.ndarray, np.ndarray]], n: int, rank: int, world: int, backend,
+                 n_layers: int = 2, slope: float = 0.5, group=None):
+        self.rank, self.world, self.backend, self.group = rank, world, backend, group
+        self.n, self.n_layers, self.slope = n, n_layers, slope
+        self.blk = -(-n // world)
+        self.r0 = min(n, rank * self.blk)
+        self.r1 = min(n, self.r0 + self.blk)
+        self.n_pad = self.blk * world          # table height: every rank's slice has blk rows
+        self.graphs, self.edges_global = [], []
+        self.hook = None
+        for (src, dst) in graphs:
+            src, dst = np.asarray(src, dtype=np.int32), np.asarray(dst, dtype=np.int32)
+            deg_out = np.bincount(src, minlength=n).astype(np.int32)
+            deg_in = np.bincount(dst, minlength=n).astype(np.int32)
+            keep = (dst >= self.r0) & (dst < self.r1)
+            owned = np.zeros(n, dtype=bool)
+            owned[self.r0:self.r1] = True
+            lg = LocalGraph(src[keep], dst[keep], deg_out, len(src), np.where(owned, deg_in, -1).astype(np.int32))
+            self.graphs.append(backend.make_graph(lg, n))
+            self.edges_global.append(len(src))
+
+    def _gather_table(self, table: torch.Tensor) -> torch.Tensor:
+        """table [n_pad, 64] with this rank's block valid -> the whole table."""
+        mine = table[self.rank * self.blk:(self.rank + 1) * self.blk]
+        return all_gather_stack(mine, self.world, self.group).reshape(self.n_pad, DG_D)
+
+    def forward(self, e0_local: torch.Tensor):
+        """e0_local: rows [r0, r1) of the layer-0 table.  Returns this rank's rows of
+        (layer sum of graph 0, sum over the other graphs of their layer sums)."""
+        be, G, L = self.backend, len(self.graphs), self.n_layers
+        stage = be.empty(self.n_pad)
+        stage[self.r0:self.r1] = e0_local
+        e0 = self._gather_table(stage)
+        sums = [be.empty(self.n_pad) for _ in range(G)]
+        prev: List[Optional[torch.Tensor]] = [None] * G
+        for l in range(L):
+            last = l == L - 1
+            flags = (DG_IN_PRESCALED if l > 0 else 0) | (0 if last else DG_OUT_PRESCALE)
+            skip_sum = l == 0 and L >= 2
+            if l == 1:
+                flags |= DG_ACC_REBUILD
+            outs, tasks = [], []
+            v = lambda t: None if t is None else t[: self.n]   # the kernels take tables of exactly n rows
+            for g in range(G):
+                e_out = None if last else be.empty(self.n_pad)
+                outs.append(e_out)
+                acc_in = None if skip_sum else (e0 if l <= 1 else sums[g])
+                tasks.append(dict(graph=self.graphs[g], x=v(e0 if l == 0 else prev[g]), e_out=v(e_out), acc_in=v(acc_in),
+                                  acc_out=None if skip_sum else v(sums[g]), flags=flags, slope=self.slope))
+            if self.hook:
+                self.hook("begin", l)
+            be.layer(tasks)
+            prev = [None if o is None else self._gather_table(o) for o in outs]
+            if self.hook:
+                self.hook("end", l)
+        het = be.sum_tables([t[: self.n] for t in sums[1:]])
+        return sums[0][self.r0:self.r1], het[self.r0:self.r1]
 
 
 class ShardedRecPropagation:
@@ -104,22 +192,7 @@ class ShardedRecPropagation:
 
     def _exchange(self, partials: torch.Tensor) -> torch.Tensor:
         """[G, n_item, 64] on every rank -> [world, G, n_item, 64] (partial sums in rank order)."""
-        if self.world == 1:
-            return partials.unsqueeze(0)
-        import torch.distributed as dist
-        if partials.is_cuda and dist.get_backend(self.group) == "gloo":
-            # single-GPU rehearsal of the multi-process path: gloo moves host memory
-            host = partials.cpu()
-            parts = [torch.empty_like(host) for _ in range(self.world)]
-            dist.all_gather(parts, host, group=self.group)
-            return torch.stack(parts, dim=0).to(partials.device)
-        if partials.is_cuda:
-            out = torch.empty((self.world,) + tuple(partials.shape), dtype=partials.dtype, device=partials.device)
-            dist.all_gather_into_tensor(out, partials, group=self.group)   # one RCCL all-gather, no re-packing
-            return out
-        parts = [torch.empty_like(partials) for _ in range(self.world)]
-        dist.all_gather(parts, partials, group=self.group)
-        return torch.stack(parts, dim=0)
+        return all_gather_stack(partials, self.world, self.group)
 
     def forward(self, e0: torch.Tensor):
         """e0: [n_loc + n_item, 64] = this rank's user rows, then the (replicated) item rows.
@@ -164,10 +237,20 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
     workload = args.workload or "industry"
     wl = dgdata.rec_workload(workload)
     inter = [wl.target] + wl.behaviours
-    prop = ShardedRecPropagation(inter, wl.n_user, wl.n_item, rank, world, HipBackend(device))
-    ue = torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)[prop.u0:prop.u1])
     ie = torch.from_numpy(dgdata.xavier_uniform(wl.n_item, 64, seed=1))
-    e0 = torch.cat([ue, ie]).to(device)
+    # item side small enough to replicate (Industry): user shards + item partial sums; otherwise row blocks
+    row_blocks = wl.n_item > 4096
+
+    def make(rk, wd):
+        if row_blocks:
+            edges = [dgdata.bipartite_edges(u, i, wl.n_user) for (u, i) in inter]
+            p = RowBlockPropagation(edges, wl.n, rk, wd, HipBackend(device))
+            full = torch.cat([torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)), ie])
+            return p, full[p.r0:p.r1].to(device)
+        p = ShardedRecPropagation(inter, wl.n_user, wl.n_item, rk, wd, HipBackend(device))
+        ue = torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)[p.u0:p.u1])
+        return p, torch.cat([ue, ie]).to(device)
+    prop, e0 = make(rank, world)
 
     events = []
 
@@ -218,8 +301,7 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
     single = None
     if world > 1 and rank == 0:
         del prop, out
-        p1 = ShardedRecPropagation(inter, wl.n_user, wl.n_item, 0, 1, HipBackend(device))
-        e1 = torch.cat([torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)), ie]).to(device)
+        p1, e1 = make(0, 1)
         for _ in range(max(2, args.warmup // 2)):
             p1.forward(e1)
         torch.cuda.synchronize()
@@ -239,12 +321,14 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}: {wl.note}", "n_user": wl.n_user, "n_item": wl.n_item,
                        "graphs": len(nnz), "directed_edges_per_graph": nnz, "layers": L,
-                       "step": "HGDM.forward propagation, user rows sharded over the ranks, one all-gather of the "
-                               "item partial sums per layer",
-                       "parallelism": f"user-row shards x{world}"},
+                       "step": ("HGDM.forward propagation, equal row blocks per rank, one all-gather of each graph's "
+                                "activation table per layer") if row_blocks else
+                               ("HGDM.forward propagation, user rows sharded over the ranks, one all-gather of the "
+                                "item partial sums per layer"),
+                       "parallelism": f"row blocks x{world}" if row_blocks else f"user-row shards x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "one sharded propagation layer on rank 0 (lds_rows_kernel + "
-                         "window_rows_kernel + hub_reduce_kernel + exchange + partial_finalize_kernel)",
+                         "traffic": None, "kernel": "one sharded propagation layer on rank 0 (propagation kernels + "
+                         "exchange + partial_finalize_kernel)",
                          "bytes_per_launch": per_rank_bytes, "ms_per_launch": layer_ms},
         }
         if single is not None:

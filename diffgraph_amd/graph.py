@@ -19,7 +19,8 @@ class CSRGraph:
     def __init__(self, src, dst, num_nodes: int, group_max: int = 0, seg_len: int = 0, out_degrees=None,
                  in_degrees=None):
         """out_degrees / in_degrees (int32[num_nodes]) override the degrees counted from the given
-        edges; a rank holding an edge shard passes the whole graph's degrees."""
+        edges; a rank holding an edge shard passes the whole graph's degrees.  in_degrees[i] < 0 marks
+        node i as not owned: the forward propagation skips that row (row-block partitions)."""
         src = np.ascontiguousarray(np.asarray(src), dtype=np.int32)
         dst = np.ascontiguousarray(np.asarray(dst), dtype=np.int32)
         if src.shape != dst.shape or src.ndim != 1:
@@ -90,7 +91,7 @@ class CSRGraph:
 
     def schedule(self) -> dict:
         c = self._export(5, 5, np.int32)
-        return {"row_order": self._export(4, self._n - int(c[4]), np.int32), "n_hub": int(c[0]), "n_wave": int(c[1]),
+        return {"row_order": self._export(4, int(c[0]) + int(c[1]) + int(c[2]), np.int32), "n_hub": int(c[0]), "n_wave": int(c[1]),
                 "n_group": int(c[2]), "n_seg": int(c[3]), "lds_split": int(c[4])}
 
     def close(self) -> None:

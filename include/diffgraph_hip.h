@@ -56,7 +56,9 @@ int dg_graph_create(int32_t n_nodes, int64_t n_edges, const int32_t *src_host,
                     dg_graph **out);
 /* Same, with the node degrees supplied by the caller (int32[n_nodes], NULL = count the given
  * edges).  A rank that holds only a shard of the edges passes the GLOBAL degrees so that its
- * norms equal the whole graph's. */
+ * norms equal the whole graph's.  in_deg_host[i] < 0 marks node i as NOT OWNED by this rank:
+ * the forward propagation then neither computes nor writes row i (a rank of a row-block
+ * partition owns one block of rows and holds only the edges that end in it). */
 int dg_graph_create_ex(int32_t n_nodes, int64_t n_edges, const int32_t *src_host,
                        const int32_t *dst_host, const int32_t *out_deg_host,
                        const int32_t *in_deg_host, int32_t group_max, int32_t seg_len,
@@ -67,9 +69,10 @@ int64_t dg_graph_num_edges(const dg_graph *g);
 /* 1 if the edge set equals its transpose (then forward and backward share one CSR). */
 int dg_graph_is_symmetric(const dg_graph *g);
 /* Copy schedule/CSR facts back to the host for tests: which = 0 rowptr[n+1], 1 colidx[nnz],
- * 2 dinv_src[n] (float bits), 3 dinv_dst[n], 4 row_order[n - lds_split],
+ * 2 dinv_src[n] (float bits), 3 dinv_dst[n], 4 row_order[n_hub + n_wave + n_group] (the owned rows;
+ * with lds_split > 0 only those from lds_split on),
  * 5 counts {n_hub,n_wave,n_group,n_seg,lds_split} (lds_split > 0: rows below it gather from an
- * LDS-resident copy of the rows above it and are not in row_order). */
+ * LDS-resident copy of the rows above it). */
 int dg_graph_export(const dg_graph *g, int which, void *dst_host, size_t dst_bytes);
 
 /* ------------------------------------------------------------------------------------

@@ -12,8 +12,11 @@ from diffgraph_amd._lib import DG_ACC_REBUILD, DG_IN_PRESCALED, DG_OUT_NORM, DG_
 class CpuBackend:
     def make_graph(self, lg, n_nodes):
         deg = torch.from_numpy(lg.degrees).float().clamp(min=1)
+        owned = None
+        if getattr(lg, "in_degrees", None) is not None:   # row-block shard: rows with in-degree -1 are not computed
+            owned = torch.nonzero(torch.from_numpy(lg.in_degrees) >= 0).flatten()
         return SimpleNamespace(src=torch.from_numpy(lg.src).long(), dst=torch.from_numpy(lg.dst).long(), n=n_nodes,
-                               dinv=torch.pow(deg, -0.5).view(-1, 1))
+                               dinv=torch.pow(deg, -0.5).view(-1, 1), owned=owned)
 
     def empty(self, rows):
         return torch.full((rows, 64), float("nan"))
@@ -34,12 +37,12 @@ class CpuBackend:
     def layer(self, tasks):
         for t in tasks:
             g, x = t["graph"], t["x"]
-            h = x if t["flags"] & DG_IN_PRESCALED else x * g.dinv
+            h = x[: g.n] if t["flags"] & DG_IN_PRESCALED else x[: g.n] * g.dinv
             s = torch.zeros_like(h).index_add_(0, g.dst, h[g.src])
-            pf = t["partial_from"] if t["partial_out"] is not None else g.n
-            if t["partial_out"] is not None:
+            pf = t["partial_from"] if t.get("partial_out") is not None else g.n
+            if t.get("partial_out") is not None:
                 t["partial_out"].copy_(s[pf:])
-            rows = slice(0, pf)
+            rows = slice(0, pf) if g.owned is None else g.owned
             self._epilogue(g, rows, s[rows], t["e_out"], t["acc_in"], t["acc_out"], t["flags"], t["slope"], x)
 
     def finalize(self, tasks):

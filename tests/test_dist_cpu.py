@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from diffgraph_amd import data as dgdata
-from diffgraph_amd.dist import ShardedRecPropagation, shard_bipartite, user_ranges
+from diffgraph_amd.dist import RowBlockPropagation, ShardedRecPropagation, shard_bipartite, user_ranges
 from oracle import ref_cpu as O
 from tests.cpu_backend import CpuBackend
 from tests.helpers import assert_rows_close, edges_t
@@ -85,3 +85,47 @@ def test_sharded_forward_matches_oracle(world):
         assert_rows_close(r[3][r[2] - r[1]:], ti, what="target items")
         assert_rows_close(r[4][r[2] - r[1]:], hi, what="heter items")
         np.testing.assert_array_equal(r[3][r[2] - r[1]:], results[0][3][results[0][2] - results[0][1]:])
+
+
+# ---------------------------------------------------------------- general row-block partition (all-gather per layer)
+def _rb_workload():
+    n_user, n_item = 157, 140      # neither side small: the case the item-partial-sum scheme does not cover
+    inter = [dgdata.synth_interactions(n_user, n_item, m, seed) for m, seed in ((700, 1), (1900, 2), (300, 3))]
+    ue = torch.from_numpy(dgdata.xavier_uniform(n_user, 64, seed=5))
+    ie = torch.from_numpy(dgdata.xavier_uniform(n_item, 64, seed=6))
+    return n_user, n_item, inter, ue, ie
+
+
+def _rb_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    n_user, n_item, inter, ue, ie = _rb_workload()
+    graphs = [dgdata.bipartite_edges(u, i, n_user) for (u, i) in inter]
+    prop = RowBlockPropagation(graphs, n_user + n_item, rank, world, CpuBackend())
+    ui, het = prop.forward(torch.cat([ue, ie])[prop.r0:prop.r1])
+    q.put((rank, prop.r0, prop.r1, ui.numpy(), het.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_block_forward_matches_oracle(world):
+    n_user, n_item, inter, ue, ie = _rb_workload()
+    tu, ti, hu, hi = O.rec_forward(edges_t(*inter[0], n_user), [edges_t(*b, n_user) for b in inter[1:]], ue, ie, 2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rb_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in results] == [min(n_user + n_item, k * -(-(n_user + n_item) // world)) for k in range(world)]
+    assert results[-1][2] == n_user + n_item
+    ui = np.concatenate([r[3] for r in results])
+    het = np.concatenate([r[4] for r in results])
+    assert_rows_close(ui, torch.cat([tu, ti]), what="row-block target")
+    assert_rows_close(het, torch.cat([hu, hi]), what="row-block heter")
