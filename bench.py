@@ -28,6 +28,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
+def measured_traffic(workload: str):
+    """HBM-side bytes per layer launch from the committed PMC passes of this same command (counters cannot be
+    read from inside the run being timed); None when no pass exists for the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return float(json.load(f)[workload]["traffic_bytes_per_layer_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +132,9 @@ def main():
         from diffgraph_amd import dist as dgdist
         res = dgdist.bench_sharded(args, rank, world, device)
         if res is not None:
+            if world == 1:
+                res["roofline"]["traffic"] = measured_traffic(args.workload)
+                res["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc passes of this command)"
             if world == 1 and not args.no_cpu_baseline:
                 from diffgraph_amd import data as dgdata
                 res["cpu_baseline"] = cpu_baseline(dgdata.rec_workload(args.workload), passes_per_call=1)
@@ -213,7 +226,9 @@ def main():
                            "+ backward + Adam; eval-mode dropout",
                    "batch": B, "loss": float(out[0].detach()), "launch": "eager" if args.no_graph else "hip-graph replay"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(workload),
+                     "traffic_source": "profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                       "command, bytes per layer launch (FETCH_SIZE doubled on gfx950)",
                      "kernel": "gcn_layer_kernel + hub_reduce_kernel (one fused propagation layer, all graphs)",
                      "bytes_per_launch": layer_bytes, "ms_per_launch": layer_ms},
     }
