@@ -1,0 +1,214 @@
+// The loss head of the recommendation model for gfx950: BPR + embedding regulariser + the
+// batch means of the two diffusion losses, forward and backward, in four small launches.
+//
+// Replaces the chain of gathers, products, reductions and (in the backward pass) sort-based
+// index_put accumulations that autograd records for HGDM.cal_loss (DiffGraph-Rec/Model.py:101-111)
+// and pairPredict (DiffGraph-Rec/Utils/Utils.py:4-8): ~100 launches of a few microseconds each.
+//
+// A batch entry is owned by a 16-lane group (one float4 of each 64-float row per lane).  The
+// backward pass first writes the per-entry gradients of the three gathered rows and counts, with
+// integer atomics, how many entries name each table row and which comes first; a second launch
+// writes the rows named once directly and, for rows named several times, lets the first entry add
+// the later ones IN BATCH ORDER: no float atomics, no sort, the same bits on every run.
+#include "dg_internal.h"
+
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kMaxBatch = 1 << 20;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sum16(float v) {  // over the 16 lanes of a group, left in every lane
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+struct head_rows {
+  f32x4 A, P, N;
+};
+
+__device__ __forceinline__ head_rows load_rows(const float *ui, const float *out_u, const float *out_i, int64_t a,
+                                               int64_t p, int64_t n, int n_user, int l) {
+  const f32x4 *U = reinterpret_cast<const f32x4 *>(ui), *OU = reinterpret_cast<const f32x4 *>(out_u),
+              *OI = reinterpret_cast<const f32x4 *>(out_i);
+  head_rows r;
+  r.A = U[a * 16 + l] + OU[a * 16 + l];                  // usrEmbeds + diff_usrEmbeds (Model.py:103)
+  r.P = U[(n_user + p) * 16 + l] + OI[p * 16 + l];       // itmEmbeds + diff_itemEmbeds (Model.py:104)
+  r.N = U[(n_user + n) * 16 + l] + OI[n * 16 + l];
+  return r;
+}
+
+// entries_f[b] = {log sigmoid(s), sigmoid(s), |A|^2, |P|^2, |N|^2, 0, 0, 0}; entries_d[b] = {row_loss_u, row_loss_i}
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float *ui, const float *out_u, const float *out_i,
+                                                       const double *rl_u, const double *rl_i, const int64_t *ancs,
+                                                       const int64_t *poss, const int64_t *negs, int n_batch, int n_user,
+                                                       float *entries_f, double *entries_d) {
+  const int b = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  if (b >= n_batch) return;
+  const int64_t a = ancs[b], p = poss[b], n = negs[b];
+  const head_rows r = load_rows(ui, out_u, out_i, a, p, n, n_user, l);
+  const float s = sum16(dot4(r.A, r.P)) - sum16(dot4(r.A, r.N));  // pairPredict
+  const float sig = 1.0f / (1.0f + expf(-s));
+  const float ra = sum16(dot4(r.A, r.A)), rp = sum16(dot4(r.P, r.P)), rn = sum16(dot4(r.N, r.N));
+  if (l == 0) {
+    float *e = entries_f + (size_t)b * 8;
+    e[0] = logf(sig); e[1] = sig; e[2] = ra; e[3] = rp; e[4] = rn; e[5] = 0.f; e[6] = 0.f; e[7] = 0.f;
+    entries_d[(size_t)b * 2] = rl_u[a];
+    entries_d[(size_t)b * 2 + 1] = rl_i[p];
+  }
+}
+
+// One workgroup: strided partial sums per thread, then a fixed tree.  results = {loss, bpr, reg, diff}.
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float *entries_f, const double *entries_d, int n_batch,
+                                                          double batch_div, double reg_coef, double *results) {
+  __shared__ double red[4][256];
+  double s_log = 0, s_reg = 0, s_du = 0, s_di = 0;
+  for (int b = threadIdx.x; b < n_batch; b += 256) {
+    const float *e = entries_f + (size_t)b * 8;
+    s_log += e[0];
+    s_reg += (double)e[2] + (double)e[3] + (double)e[4];
+    s_du += entries_d[(size_t)b * 2];
+    s_di += entries_d[(size_t)b * 2 + 1];
+  }
+  red[0][threadIdx.x] = s_log; red[1][threadIdx.x] = s_reg; red[2][threadIdx.x] = s_du; red[3][threadIdx.x] = s_di;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double bpr = -red[0][0] / batch_div;
+    const double reg = red[1][0] * reg_coef / batch_div;
+    const double diff = red[2][0] / n_batch + red[3][0] / n_batch;
+    results[0] = bpr + reg + diff; results[1] = bpr; results[2] = reg; results[3] = diff;
+  }
+}
+
+// Per-entry gradients of the three gathered rows -> scratch [3][n_batch][64]; and, per table row,
+// how many entries of its list name it (cnt) and which of them comes first (tag = list length -
+// entry index, kept with an integer max).  The user list is ancs, the item list poss then negs.
+__global__ __launch_bounds__(256) void head_bwd_entries_kernel(const float *ui, const float *out_u, const float *out_i,
+                                                               const int64_t *ancs, const int64_t *poss,
+                                                               const int64_t *negs, int n_batch, int n_user, int n_rows,
+                                                               double batch_div, double reg_coef, const float *entries_f,
+                                                               const double *g, float *scratch, int *tag, int *cnt) {
+  const int b = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  if (b >= n_batch) return;
+  const int64_t a = ancs[b], p = poss[b], n = negs[b];
+  const head_rows r = load_rows(ui, out_u, out_i, a, p, n, n_user, l);
+  const float c_bpr = (float)((g[0] + g[1]) / batch_div);
+  const float c_reg = (float)((g[0] + g[2]) * 2.0 * reg_coef / batch_div);
+  const float ds = -c_bpr * (1.0f - entries_f[(size_t)b * 8 + 1]);  // d(-log sigmoid(s))/ds = -(1 - sigmoid(s))
+  f32x4 *G = reinterpret_cast<f32x4 *>(scratch);
+  G[((size_t)0 * n_batch + b) * 16 + l] = (r.P - r.N) * ds + r.A * c_reg;
+  G[((size_t)1 * n_batch + b) * 16 + l] = r.A * ds + r.P * c_reg;
+  G[((size_t)2 * n_batch + b) * 16 + l] = r.A * (-ds) + r.N * c_reg;
+  if (l == 0) {
+    atomicMax(tag + a, n_batch - b);
+    atomicAdd(cnt + a, 1);
+  } else if (l == 1) {
+    atomicMax(tag + n_user + p, 2 * n_batch - b);
+    atomicAdd(cnt + n_user + p, 1);
+  } else if (l == 2) {
+    atomicMax(tag + n_user + n, n_batch - b);
+    atomicAdd(cnt + n_user + n, 1);
+  }
+}
+
+// Entry e of the user list or of the item list writes its row of the gradient tables when it is
+// the only entry naming that row; when several do, the first of them adds the later ones in list
+// order (found by scanning the list) and the others leave.
+__global__ __launch_bounds__(256) void head_scatter_kernel(const int64_t *ancs, const int64_t *poss, const int64_t *negs,
+                                                           int n_batch, int n_user, const double *g, const float *scratch,
+                                                           const int *tag, const int *cnt, float *d_ui, float *d_out_u,
+                                                           float *d_out_i, double *d_rl_u, double *d_rl_i) {
+  const int e_all = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15, q = (threadIdx.x & 63) >> 4;
+  if (e_all >= 3 * n_batch) return;
+  const bool user = e_all < n_batch;
+  const int e = user ? e_all : e_all - n_batch, m = user ? n_batch : 2 * n_batch;
+  const int64_t *list0 = user ? ancs : poss;            // list entry j: j < n_batch ? list0[j] : negs[j - n_batch]
+  const int row = (int)(e < n_batch ? list0[e] : negs[e - n_batch]);
+  const int trow = user ? row : n_user + row;
+  const int c = cnt[trow];
+  if (c > 1 && m - tag[trow] != e) return;  // an earlier entry owns this row (the whole group leaves)
+  const f32x4 *G = reinterpret_cast<const f32x4 *>(scratch) + (user ? (size_t)0 : (size_t)n_batch * 16);
+  f32x4 acc = G[(size_t)e * 16 + l];
+  int n_loss = user || e < n_batch ? 1 : 0;  // entries that carry a diffusion-loss row: ancs, poss
+  if (c > 1) {
+    int left = c - 1;
+    for (int j0 = (e + 1) & ~15; left > 0 && j0 < m; j0 += 16) {
+      const int j = j0 + l;
+      const bool hit = j > e && j < m && (int)(j < n_batch ? list0[j] : negs[j - n_batch]) == row;
+      unsigned mask = (unsigned)(__ballot(hit) >> (16 * q)) & 0xffffu;
+      while (mask) {
+        const int jj = j0 + __builtin_ctz(mask);
+        mask &= mask - 1;
+        acc += G[(size_t)jj * 16 + l];
+        n_loss += (user || jj < n_batch) ? 1 : 0;
+        --left;
+      }
+    }
+  }
+  f32x4 *DU = reinterpret_cast<f32x4 *>(d_ui);
+  DU[(size_t)trow * 16 + l] = acc;
+  if (user) {
+    reinterpret_cast<f32x4 *>(d_out_u)[(size_t)row * 16 + l] = acc;
+    if (l == 0) d_rl_u[row] = (g[0] + g[3]) * n_loss / n_batch;
+  } else {
+    reinterpret_cast<f32x4 *>(d_out_i)[(size_t)row * 16 + l] = acc;
+    if (l == 0) d_rl_i[row] = (g[0] + g[3]) * n_loss / n_batch;
+  }
+}
+
+}  // namespace
+
+extern "C" int dg_rec_head_fwd(const float *ui, const float *out_u, const float *out_i, const double *row_loss_u,
+                               const double *row_loss_i, const int64_t *ancs, const int64_t *poss, const int64_t *negs,
+                               int32_t n_batch, int32_t n_user, int32_t n_item, double batch_div, double reg_coef,
+                               int32_t d, float *entries_f, double *entries_d, double *results, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_rec_head_fwd: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!ui || !out_u || !out_i || !row_loss_u || !row_loss_i || !ancs || !poss || !negs || !entries_f || !entries_d || !results)
+    return dg_fail(DG_ERR_ARG, "dg_rec_head_fwd: NULL argument");
+  if (n_batch <= 0 || n_batch > kMaxBatch) return dg_fail(DG_ERR_SIZE, "dg_rec_head_fwd: n_batch must be in [1,%d] (got %d)", kMaxBatch, n_batch);
+  if (n_user <= 0 || n_item <= 0 || batch_div == 0.0) return dg_fail(DG_ERR_ARG, "dg_rec_head_fwd: bad sizes");
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ui, out_u, out_i,
+                     row_loss_u, row_loss_i, ancs, poss, negs, n_batch, n_user, entries_f, entries_d);
+  hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, entries_f, entries_d, n_batch, batch_div,
+                     reg_coef, results);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dg_rec_head_bwd(const float *ui, const float *out_u, const float *out_i, const int64_t *ancs,
+                               const int64_t *poss, const int64_t *negs, int32_t n_batch, int32_t n_user, int32_t n_item,
+                               double batch_div, double reg_coef, int32_t d, const float *entries_f, const double *g,
+                               float *scratch, int32_t *row_tags, float *d_ui, float *d_out_u, float *d_out_i,
+                               double *d_row_loss_u, double *d_row_loss_i, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_rec_head_bwd: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!ui || !out_u || !out_i || !ancs || !poss || !negs || !entries_f || !g || !scratch || !row_tags || !d_ui || !d_out_u ||
+      !d_out_i || !d_row_loss_u || !d_row_loss_i)
+    return dg_fail(DG_ERR_ARG, "dg_rec_head_bwd: NULL argument");
+  if (n_batch <= 0 || n_batch > kMaxBatch) return dg_fail(DG_ERR_SIZE, "dg_rec_head_bwd: n_batch must be in [1,%d] (got %d)", kMaxBatch, n_batch);
+  if (n_user <= 0 || n_item <= 0 || batch_div == 0.0) return dg_fail(DG_ERR_ARG, "dg_rec_head_bwd: bad sizes");
+  if (((uintptr_t)d_ui | (uintptr_t)d_out_u | (uintptr_t)d_out_i | (uintptr_t)scratch) & 15)
+    return dg_fail(DG_ERR_ARG, "dg_rec_head_bwd: gradient tables and scratch must be 16-byte aligned");
+  const int n_rows = n_user + n_item;
+  int *tag = row_tags, *cnt = row_tags + n_rows;
+  hipLaunchKernelGGL(head_bwd_entries_kernel, dim3((n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ui, out_u, out_i,
+                     ancs, poss, negs, n_batch, n_user, n_rows, batch_div, reg_coef, entries_f, g, scratch, tag, cnt);
+  hipLaunchKernelGGL(head_scatter_kernel, dim3((3 * n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ancs, poss, negs,
+                     n_batch, n_user, g, scratch, tag, cnt, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
+  DG_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,270 @@
+// Weight gradients of the denoiser MLP for gfx950, from the four [n][64] tables the loss
+// backward kernel leaves behind (dout_tot, hid, dpre, xn) and the per-row timesteps.
+//
+// Replaces what autograd records for the three nn.Linear layers of Denoise
+// (DiffGraph-Rec/Model.py:184-191, used at :218-232) when training_losses2 is differentiated
+// (loss.backward(), DiffGraph-Rec/main.py:127):
+//     dW_out          = dout^T . hid            db_out = colsum(dout)
+//     dW_in[:, :64]   = dpre^T . xn             db_in  = colsum(dpre)
+//     dW_in[:, 64:72] = dpre^T . emb[ts]        (emb[t] = emb_layer([cos(t f), sin(t f)]), 8 wide)
+//     dW_emb          = W_in[:,64:72]^T . (dpre^T . te[ts])      db_emb = W_in[:,64:72]^T . db_in
+// All of them contract over the n table rows, so the rows are the K dimension of exact-fp32
+// v_mfma_f32_16x16x4_f32 tiles: a lane (j = lane&15, k = lane>>4) loads one float4 of table row
+// base+k -- 16 lanes cover a whole 256-B row, a wavefront load four rows -- and component e of
+// that float4 (feature 4j+e) is the operand of the tile with index e.  Sixteen 16x16 tiles make
+// one 64x64 product.  Every workgroup sums a contiguous strip of rows; a second launch adds the
+// per-workgroup partial results in workgroup order, so the gradients are the same bits on every
+// run (no float atomics) and nothing depends on a BLAS workspace or semaphore.
+#include "dg_internal.h"
+
+#include <math.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kGroups = 256;          // workgroups of the partial launch = partial results to add
+constexpr int kTabCols = 16;          // per-timestep operand row: emb[t] (8) | te[t] (8)
+// floats of one partial result: dW_out, dW_in[:, :64], dpre^T.tab (64x16), db_out, db_in
+constexpr int kPartWout = 0, kPartWin = 4096, kPartTab = 8192, kPartBout = 9216, kPartBin = 9280;
+constexpr int kPartFloats = 9344;
+
+struct wg_args {
+  const float *dout, *hid, *dpre, *xn;
+  const int64_t *ts;
+  const float *tab;   // [n_steps][16]
+  float *partials;    // [kGroups][kPartFloats]
+  int64_t n;
+  int32_t n_steps;
+  int64_t rows_per_group;  // multiple of 16
+};
+
+struct tab_args {
+  const float *w_emb, *b_emb;
+  float freqs[4];
+  int32_t n_steps;
+};
+
+// tab[t] = [ emb_layer(te_t) | te_t ],  te_t = [cos(t f_0..3), sin(t f_0..3)]  (Model.py:215-218)
+__global__ __launch_bounds__(256) void wgrad_tab_kernel(tab_args a, float *__restrict__ tab) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.n_steps) return;
+  float te[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float arg = (float)t * a.freqs[k];
+    te[k] = cosf(arg);
+    te[k + 4] = sinf(arg);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float emb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) emb += te[k] * a.w_emb[e * 8 + k];
+    tab[t * kTabCols + e] = emb + a.b_emb[e];
+    tab[t * kTabCols + 8 + e] = te[e];
+  }
+}
+
+// acc[mb][nb] += A-tile mb (features 4j+mb of the `a` rows) ^T . B-tile nb (features 4j+nb of the `b` rows)
+__device__ __forceinline__ void mma64(const f32x4 a, const f32x4 b, f32x4 (&acc)[4][4]) {
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+}
+
+// Element (o, i) of a 64x64 product sits in acc[mb][nb][r] of lane l with
+//   o = 16 (l>>4) + 4 r + mb,  i = 4 (l&15) + nb:   the four nb of one (mb, r) are a contiguous float4.
+__device__ __forceinline__ void store64(float *dst, int lane, const f32x4 (&acc)[4][4]) {
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * (lane >> 4) + 4 * r + mb;
+      *reinterpret_cast<f32x4 *>(dst + o * 64 + 4 * (lane & 15)) =
+          f32x4{acc[mb][0][r], acc[mb][1][r], acc[mb][2][r], acc[mb][3][r]};
+    }
+}
+
+struct wg_operands {
+  f32x4 a, b;
+  float t;
+};
+
+__device__ __forceinline__ wg_operands load_operands(const wg_args &a, const float *A, const float *B, bool with_tab,
+                                                     int64_t row, int64_t r1, int j) {
+  wg_operands o = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, 0.f};
+  if (row < r1) {
+    o.a = *reinterpret_cast<const f32x4 *>(A + row * DG_D + 4 * j);
+    o.b = *reinterpret_cast<const f32x4 *>(B + row * DG_D + 4 * j);
+    if (with_tab) {
+      const int t = min(max((int)a.ts[row], 0), a.n_steps - 1);
+      o.t = a.tab[t * kTabCols + j];
+    }
+  }
+  return o;
+}
+
+// Waves 0..3 of a workgroup: dout^T.hid + colsum(dout); waves 4..7: dpre^T.xn, dpre^T.tab[ts],
+// colsum(dpre).  The four waves of a half take every fourth 4-row quad of the workgroup's strip
+// (the next quad's rows are requested before the current one is multiplied) and hand their sums
+// to the half's first wave through LDS, one after the other.
+__global__ __launch_bounds__(512) void wgrad_partial_kernel(const wg_args a) {
+  __shared__ f32x4 xch[2][21][64];  // per half: 16 + 4 + 1 accumulator float4s per lane
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = wave >> 2, sub = wave & 3;
+  const int j = lane & 15, k = lane >> 4;
+  const bool with_tab = half == 1;
+  const float *A = half == 0 ? a.dout : a.dpre;
+  const float *B = half == 0 ? a.hid : a.xn;
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_group;
+  const int64_t r1 = min(r0 + a.rows_per_group, a.n);
+
+  f32x4 acc[4][4], acc_t[4], csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    acc_t[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int64_t q = r0 + 4 * sub;
+  wg_operands cur = load_operands(a, A, B, with_tab, q + k, r1, j);
+  for (; q < r1; q += 16) {
+    const wg_operands nxt = load_operands(a, A, B, with_tab, q + 16 + k, r1, j);
+    mma64(cur.a, cur.b, acc);
+    csum += cur.a;
+    if (with_tab) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+        acc_t[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[mb], cur.t, acc_t[mb], 0, 0, 0);
+    }
+    cur = nxt;
+  }
+  // column sums: add the four k-lanes that share j (fixed order)
+  for (int c = 0; c < 4; ++c) {
+    float v = csum[c];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    csum[c] = v;
+  }
+  for (int w = 1; w < 4; ++w) {
+    if (sub == w) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) xch[half][mb * 4 + nb][lane] = acc[mb][nb];
+        xch[half][16 + mb][lane] = acc_t[mb];
+      }
+      xch[half][20][lane] = csum;
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] += xch[half][mb * 4 + nb][lane];
+        acc_t[mb] += xch[half][16 + mb][lane];
+      }
+      csum += xch[half][20][lane];
+    }
+    __syncthreads();
+  }
+  if (sub != 0) return;
+  float *P = a.partials + (size_t)blockIdx.x * kPartFloats;
+  store64(P + (half == 0 ? kPartWout : kPartWin), lane, acc);
+  if (k == 0) *reinterpret_cast<f32x4 *>(P + (half == 0 ? kPartBout : kPartBin) + 4 * j) = csum;
+  if (half == 1) {
+    // (dpre^T . tab)[o][c]: acc_t[mb][r] of lane l is o = 16 (l>>4) + 4 r + mb, c = l & 15
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[kPartTab + (16 * k + 4 * r + mb) * kTabCols + j] = acc_t[mb][r];
+  }
+}
+
+struct fin_args {
+  const float *partials;
+  float *d_w_in, *d_b_in, *d_w_out, *d_b_out;
+  float *mk;  // [64][8] dpre^T . te[ts], for wgrad_emb_kernel
+};
+
+// One thread per float of a partial result: adds the kGroups partials in order and writes the
+// float where it belongs.
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const fin_args a) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= kPartFloats) return;
+  float s = 0.f;
+  for (int g = 0; g < kGroups; ++g) s += a.partials[(size_t)g * kPartFloats + f];
+  if (f < kPartWin) a.d_w_out[f] = s;
+  else if (f < kPartTab) {
+    const int o = (f - kPartWin) >> 6, i = (f - kPartWin) & 63;
+    a.d_w_in[o * 72 + i] = s;
+  } else if (f < kPartBout) {
+    const int o = (f - kPartTab) >> 4, c = (f - kPartTab) & 15;
+    if (c < 8) a.d_w_in[o * 72 + 64 + c] = s;
+    else a.mk[o * 8 + (c - 8)] = s;
+  } else if (f < kPartBin) a.d_b_out[f - kPartBout] = s;
+  else a.d_b_in[f - kPartBin] = s;
+}
+
+// dW_emb[e][c] = sum_o W_in[o][64+e] mk[o][c];  db_emb[e] = sum_o W_in[o][64+e] db_in[o]
+__global__ __launch_bounds__(128) void wgrad_emb_kernel(const float *__restrict__ w_in, const float *__restrict__ mk,
+                                                        const float *__restrict__ d_b_in, float *__restrict__ d_w_emb,
+                                                        float *__restrict__ d_b_emb) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    const int e = t >> 3, c = t & 7;
+    float s = 0.f;
+    for (int o = 0; o < 64; ++o) s += w_in[o * 72 + 64 + e] * mk[o * 8 + c];
+    d_w_emb[t] = s;
+  } else if (t < 72) {
+    const int e = t - 64;
+    float s = 0.f;
+    for (int o = 0; o < 64; ++o) s += w_in[o * 72 + 64 + e] * d_b_in[o];
+    d_b_emb[e] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t dg_denoiser_wgrad_workspace(int32_t n_steps) {
+  if (n_steps <= 0) return 0;
+  return ((size_t)n_steps * kTabCols + 64 * 8 + (size_t)kGroups * kPartFloats) * sizeof(float);
+}
+
+extern "C" int dg_denoiser_wgrad(const dg_denoiser *dn, int32_t n_steps, const int64_t *ts, const float *dout_tot,
+                                 const float *hid, const float *dpre, const float *xn, int64_t n, int32_t d,
+                                 void *workspace, size_t workspace_bytes, float *d_w_emb, float *d_b_emb, float *d_w_in,
+                                 float *d_b_in, float *d_w_out, float *d_b_out, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_denoiser_wgrad: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!dn || !dn->w_emb || !dn->b_emb || !dn->w_in || !dn->freqs_host || !ts || !dout_tot || !hid || !dpre || !xn ||
+      !workspace || !d_w_emb || !d_b_emb || !d_w_in || !d_b_in || !d_w_out || !d_b_out)
+    return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: NULL argument");
+  if (n_steps <= 0 || n < 0) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: bad sizes");
+  if (workspace_bytes < dg_denoiser_wgrad_workspace(n_steps))
+    return dg_fail(DG_ERR_SIZE, "dg_denoiser_wgrad: workspace of %zu bytes, %zu needed", workspace_bytes,
+                   dg_denoiser_wgrad_workspace(n_steps));
+  if (((uintptr_t)dout_tot | (uintptr_t)hid | (uintptr_t)dpre | (uintptr_t)xn | (uintptr_t)workspace) & 15)
+    return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: tables and workspace must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  float *tab = (float *)workspace;
+  float *mk = tab + (size_t)n_steps * kTabCols;
+  float *partials = mk + 64 * 8;
+  tab_args ta;
+  ta.w_emb = dn->w_emb; ta.b_emb = dn->b_emb; ta.n_steps = n_steps;
+  for (int k = 0; k < 4; ++k) ta.freqs[k] = dn->freqs_host[k];
+  hipLaunchKernelGGL(wgrad_tab_kernel, dim3((n_steps + 255) / 256), dim3(256), 0, s, ta, tab);
+  wg_args a;
+  a.dout = dout_tot; a.hid = hid; a.dpre = dpre; a.xn = xn; a.ts = ts; a.tab = tab; a.partials = partials;
+  a.n = n; a.n_steps = n_steps;
+  a.rows_per_group = ((n + kGroups - 1) / kGroups + 15) / 16 * 16;
+  if (a.rows_per_group == 0) a.rows_per_group = 16;
+  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(kGroups), dim3(512), 0, s, a);
+  fin_args f;
+  f.partials = partials; f.d_w_in = d_w_in; f.d_b_in = d_b_in; f.d_w_out = d_w_out; f.d_b_out = d_b_out; f.mk = mk;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((kPartFloats + 255) / 256), dim3(256), 0, s, f);
+  hipLaunchKernelGGL(wgrad_emb_kernel, dim3(1), dim3(128), 0, s, dn->w_in, mk, d_b_in, d_w_emb, d_b_emb);
+  DG_HIP(hipGetLastError());
+  return 0;
+}

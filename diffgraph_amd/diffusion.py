@@ -75,9 +75,8 @@ class Denoise(nn.Module):
 
 class _DiffusionLossFn(torch.autograd.Function):
     """training_losses2 as one differentiable op: HIP kernels for the per-row work in both
-    directions; the weight gradients are [64 x n].[n x 64] library GEMMs over tables the
-    backward kernel writes, and the 8-wide time-embedding branch is differentiated with
-    torch ops on its [n_steps, 8] tensors."""
+    directions, the weight gradients included (ops.denoiser_wgrad over tables the backward
+    kernel writes)."""
 
     @staticmethod
     def forward(ctx, target, x_start, noise, ts, w_emb, b_emb, w_in, b_in, w_out, b_out, gd, model, validate):
@@ -89,7 +88,6 @@ class _DiffusionLossFn(torch.autograd.Function):
         lw = gd._dev("loss_weight", dev, torch.float64)
         target, x_start = target.contiguous(), x_start.contiguous()
         row_loss, out, _ = ops.diffusion_loss_fwd(p, target, x_start, noise, ts, sa, sb, lw, validate=validate)
-        gd.time_embedding_table(dev, model.time_emb_dim)  # built here so that the backward does no host->device copy
         ctx.save_for_backward(target, x_start, noise if noise is not None else x_start, ts)
         ctx.aux = (gd, model, p, sa, sb, lw)
         return row_loss, out
@@ -105,20 +103,7 @@ class _DiffusionLossFn(torch.autograd.Function):
         g_out = None if g_out is None else g_out.contiguous()
         d_x, d_tgt, dout, hid, dpre, xn = ops.diffusion_loss_bwd(p, target, x_start, noise, ts, sa, sb, lw,
                                                                  g_row.contiguous(), g_out)
-        w_emb, b_emb, w_in = model.emb_layer.weight, model.emb_layer.bias, model.in_layers[0].weight
-        d_w_out = ops.splitk_tn(dout, hid)
-        d_b_out = dout.sum(0)
-        d_w_in_x = ops.splitk_tn(dpre, xn)
-        d_tb = torch.zeros(gd.steps, DG_D, device=dev).index_add_(0, ts, dpre[:n])
-        # time-embedding branch (Model.py:215-220): te -> emb_layer -> last 8 input columns of in_layers[0]
-        te = gd.time_embedding_table(dev, model.time_emb_dim)
-        emb = te @ w_emb.detach().t() + b_emb.detach()
-        d_b_in = d_tb.sum(0)
-        d_w_in_t = d_tb.t() @ emb
-        d_emb = d_tb @ w_in.detach()[:, DG_D:]
-        d_w_emb = d_emb.t() @ te
-        d_b_emb = d_emb.sum(0)
-        d_w_in = torch.cat([d_w_in_x, d_w_in_t], dim=1)
+        d_w_emb, d_b_emb, d_w_in, d_b_in, d_w_out, d_b_out = ops.denoiser_wgrad(p, gd.steps, ts, dout, hid, dpre, xn)
         return d_tgt, d_x, None, None, d_w_emb, d_b_emb, d_w_in, d_b_in, d_w_out, d_b_out, None, None, None
 
 
@@ -175,18 +160,6 @@ class GaussianDiffusion(nn.Module):
             self._dev_tables[key] = t
         return t
 
-    def time_embedding_table(self, device, dim: int = 8) -> torch.Tensor:
-        """[steps, dim] sinusoidal embedding of every timestep (Model.py:215-217), cached per device."""
-        key = ("te", str(device), dim)
-        te = self._dev_tables.get(key)
-        if te is None:
-            half = dim // 2
-            freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
-            arg = torch.arange(self.steps, dtype=torch.float32)[:, None] * freqs[None]
-            te = torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1).to(device)
-            self._dev_tables[key] = te
-        return te
-
     # -- reference API ------------------------------------------------------------------
     def _extract_into_tensor(self, arr, timesteps, broadcast_shape):  # Model.py:307-312
         res = arr.to(timesteps.device)[timesteps].float()
@@ -240,6 +213,12 @@ class GaussianDiffusion(nn.Module):
                                          self._dev("posterior_mean_coef2", dev))
 
     def training_losses2(self, model, targetEmbeds, x_start, batch, ts=None, noise=None):  # Model.py:348-366
+        row_loss, out = self.training_losses_rows(model, targetEmbeds, x_start, ts, noise)
+        return row_loss[batch], out
+
+    def training_losses_rows(self, model, targetEmbeds, x_start, ts=None, noise=None):
+        """training_losses2 before its final `[batch]` gather (Model.py:348-365): the fp64 SNR-weighted loss of
+        EVERY row and the denoiser output."""
         n = x_start.size(0)
         dev = x_start.device
         validate = ts is not None  # caller-supplied timesteps are range-checked (one host sync)
@@ -254,17 +233,16 @@ class GaussianDiffusion(nn.Module):
                                     "(the reference runs with dropout off after its first epoch)")
         if torch.is_grad_enabled() and (xs.requires_grad or targetEmbeds.requires_grad
                                         or any(q.requires_grad for q in model.parameters())):
-            row_loss, out = _DiffusionLossFn.apply(
+            return _DiffusionLossFn.apply(
                 targetEmbeds, xs, noise, ts, model.emb_layer.weight, model.emb_layer.bias, model.in_layers[0].weight,
                 model.in_layers[0].bias, model.out_layers[0].weight, model.out_layers[0].bias, self, model, validate)
-            return row_loss[batch], out
         p = model.params(norm)
         p.time_bias(self.steps, refresh=True)
         sa = self._dev("sqrt_alphas_cumprod", dev) if self.noise_scale != 0 else None
         sb = self._dev("sqrt_one_minus_alphas_cumprod", dev) if self.noise_scale != 0 else None
         row_loss, out, _ = ops.diffusion_loss_fwd(p, targetEmbeds.contiguous(), xs, noise, ts, sa, sb,
                                                   self._dev("loss_weight", dev, torch.float64), validate=validate)
-        return row_loss[batch], out
+        return row_loss, out
 
     def mean_flat(self, tensor):  # Model.py:368-369
         return tensor.mean(dim=list(range(1, len(tensor.shape))))

@@ -73,6 +73,29 @@ class _PropagateFn(torch.autograd.Function):
         return ops.sum_tables(d_sum + w), None
 
 
+class _RecHeadFn(torch.autograd.Function):
+    """The loss head of cal_loss (Model.py:101-111) as one differentiable op over the whole tables: residual
+    add, the three batch gathers, pairPredict, BPR, the regulariser and the batch means of the two diffusion
+    losses.  Returns fp64[4] = (loss, bprLoss, regLoss, diff_loss)."""
+
+    @staticmethod
+    def forward(ctx, ui, out_u, out_i, row_loss_u, row_loss_i, ancs, poss, negs, n_user, batch_div, reg):
+        ui, out_u, out_i = ui.contiguous(), out_u.contiguous(), out_i.contiguous()
+        results, ent_f = ops.rec_head_fwd(ui, out_u, out_i, row_loss_u.contiguous(), row_loss_i.contiguous(), ancs, poss,
+                                          negs, n_user, batch_div, reg)
+        ctx.save_for_backward(ui, out_u, out_i, ancs, poss, negs, ent_f)
+        ctx.consts = (n_user, batch_div, reg)
+        return results
+
+    @staticmethod
+    def backward(ctx, g):
+        ui, out_u, out_i, ancs, poss, negs, ent_f = ctx.saved_tensors
+        n_user, batch_div, reg = ctx.consts
+        d_ui, d_out_u, d_out_i, d_rl_u, d_rl_i = ops.rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user, batch_div, reg,
+                                                                  ent_f, g.contiguous())
+        return d_ui, d_out_u, d_out_i, d_rl_u, d_rl_i, None, None, None, None, None, None
+
+
 class HGDM(nn.Module):
     def __init__(self, data_handler, args=None, device="cuda"):
         super().__init__()
@@ -154,22 +177,17 @@ class HGDM(nn.Module):
 
     def cal_loss(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None):  # Model.py:94-111
         args = self.args
-        usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = self.forward()
+        ui, het = self.propagate(self.embedding_table)
+        nu = self.n_user
+        usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = ui[:nu], ui[nu:], het[:nu], het[nu:]
         dp = self.diffusion_process
-        u_diff_loss, diff_usrEmbeds = dp.training_losses2(self.usr_denoiser, usrEmbeds, h_usrEmbeds, ancs, ts_u, noise_u)
-        i_diff_loss, diff_itemEmbeds = dp.training_losses2(self.item_denoiser, itmEmbeds, h_itemEmbeds, poss, ts_i, noise_i)
-        diff_loss = u_diff_loss.mean() + i_diff_loss.mean()
-        usrEmbeds = usrEmbeds + diff_usrEmbeds
-        itmEmbeds = itmEmbeds + diff_itemEmbeds
-        ancEmbeds, posEmbeds, negEmbeds = usrEmbeds[ancs], itmEmbeds[poss], itmEmbeds[negs]
-        scoreDiff = pairPredict(ancEmbeds, posEmbeds, negEmbeds)
-        bprLoss = -(scoreDiff).sigmoid().log().sum() / args.batch
-        # ||x||_2^2 written as sum(x^2): same value as the reference's torch.norm(x) ** 2 (Model.py:109) to
-        # rounding, and safe under HIP-graph replay (torch's full-tensor norm reduction is not, on this build)
-        sq = lambda x: x.square().sum()
-        regLoss = ((sq(ancEmbeds) + sq(posEmbeds) + sq(negEmbeds)) * args.reg) / args.batch
-        loss = bprLoss + regLoss + diff_loss
-        return loss, bprLoss, regLoss, diff_loss
+        # everything after the two denoiser passes is one fused op over the full tables (see _RecHeadFn)
+        row_loss_u, diff_usrEmbeds = dp.training_losses_rows(self.usr_denoiser, usrEmbeds, h_usrEmbeds, ts_u, noise_u)
+        row_loss_i, diff_itemEmbeds = dp.training_losses_rows(self.item_denoiser, itmEmbeds, h_itemEmbeds, ts_i, noise_i)
+        ancs, poss, negs = (v.long().contiguous() for v in (ancs, poss, negs))
+        res = _RecHeadFn.apply(ui, diff_usrEmbeds, diff_itemEmbeds, row_loss_u, row_loss_i, ancs, poss, negs, self.n_user,
+                               float(args.batch), float(args.reg))
+        return res[0], res[1], res[2], res[3]
 
     def predict(self):  # Model.py:112-118
         usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = self.forward()

@@ -319,16 +319,6 @@ def diffusion_loss_fwd(dn: DenoiserParams, target: torch.Tensor, x_start: torch.
     return row_loss, out, x_t
 
 
-GEMM_SPLIT = 64
-
-
-def splitk_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a^T @ b for tall [n_pad,64] tables as GEMM_SPLIT independent slices summed afterwards (a single
-    [64 x n].[n x 64] GEMM leaves the library one tile of work per CU or less)."""
-    s = GEMM_SPLIT
-    return torch.bmm(a.view(s, -1, a.shape[1]).transpose(1, 2), b.view(s, -1, b.shape[1])).sum(0)
-
-
 def diffusion_loss_bwd(dn: DenoiserParams, target, x_start, noise, ts, sqrt_ac, sqrt_1mac, loss_w, g_row_loss, g_out):
     """Backward of diffusion_loss_fwd.  Returns (d_x_start, d_target, dout_tot, hid, dpre, xn)."""
     n = x_start.shape[0]
@@ -339,17 +329,88 @@ def diffusion_loss_bwd(dn: DenoiserParams, target, x_start, noise, ts, sqrt_ac, 
     if g_out is not None:
         _table(g_out, "grad of out", n)
     tb = dn.time_bias(n_steps)
-    outs = [torch.empty_like(x_start) for _ in range(2)]
-    # the four GEMM operand tables are padded with zero rows to a multiple of GEMM_SPLIT rows so the
-    # caller can run the [64 x n].[n x 64] reductions as a batched (split-K) GEMM
-    n_pad = -(-n // GEMM_SPLIT) * GEMM_SPLIT
-    for _ in range(4):
-        t = torch.empty((n_pad, DG_D), dtype=torch.float32, device=x_start.device)
-        t[n:].zero_()
-        outs.append(t)
+    outs = [torch.empty_like(x_start) for _ in range(6)]
     rc = _lib.load().dg_diffusion_loss_bwd(C.byref(dn.c), tb.data_ptr(), n_steps, target.data_ptr(), x_start.data_ptr(),
                                            _ptr(noise) if sqrt_ac is not None else None, ts.data_ptr(), _ptr(sqrt_ac),
                                            _ptr(sqrt_1mac), loss_w.data_ptr(), g_row_loss.data_ptr(), _ptr(g_out), n, DG_D,
                                            *[o.data_ptr() for o in outs], _lib.stream_ptr(x_start.device))
     _lib.check(rc, "dg_diffusion_loss_bwd")
     return tuple(outs)
+
+
+def denoiser_wgrad(dn: DenoiserParams, n_steps: int, ts, dout, hid, dpre, xn):
+    """Weight gradients of the denoiser from the tables of diffusion_loss_bwd.
+    Returns (d_w_emb [8,8], d_b_emb [8], d_w_in [64,72], d_b_in [64], d_w_out [64,64], d_b_out [64])."""
+    n = dout.shape[0]
+    for nm, t in (("dout", dout), ("hid", hid), ("dpre", dpre), ("xn", xn)):
+        _table(t, nm, n)
+    _vec(ts, "timesteps", torch.int64, n)
+    lib = _lib.load()
+    dev = dout.device
+    ws_bytes = int(lib.dg_denoiser_wgrad_workspace(n_steps))
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+    flat = torch.empty(64 + 8 + DG_D * 72 + DG_D + DG_D * DG_D + DG_D, dtype=torch.float32, device=dev)
+    parts, o = [], 0
+    for shape in ((8, 8), (8,), (DG_D, 72), (DG_D,), (DG_D, DG_D), (DG_D,)):
+        k = math.prod(shape)
+        parts.append(flat[o: o + k].view(shape))
+        o += k
+    rc = lib.dg_denoiser_wgrad(C.byref(dn.c), n_steps, ts.data_ptr(), dout.data_ptr(), hid.data_ptr(), dpre.data_ptr(),
+                               xn.data_ptr(), n, DG_D, ws.data_ptr(), ws_bytes, *[p.data_ptr() for p in parts],
+                               _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_denoiser_wgrad")
+    return tuple(parts)
+
+
+# ------------------------------------------------------------------------------ loss head (a10)
+def _index_vec(v: torch.Tensor, name: str, n: int) -> None:
+    if v.dtype != torch.int64 or not v.is_cuda or not v.is_contiguous() or v.numel() != n:
+        raise DiffGraphHipError(f"{name}: expected a contiguous int64 GPU vector of {n} elements")
+
+
+def rec_head_fwd(ui, out_u, out_i, row_loss_u, row_loss_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float):
+    """Loss head of HGDM.cal_loss (Model.py:101-111).  Returns (results fp64[4] = loss, bpr, reg, diff; entries_f)."""
+    n_item = ui.shape[0] - n_user
+    B = ancs.numel()
+    _table(ui, "ui")
+    _table(out_u, "out_u", n_user)
+    _table(out_i, "out_i", n_item)
+    _vec(row_loss_u, "row_loss_u", torch.float64, n_user)
+    _vec(row_loss_i, "row_loss_i", torch.float64, n_item)
+    for v, nm in ((ancs, "ancs"), (poss, "poss"), (negs, "negs")):
+        _index_vec(v, nm, B)
+    dev = ui.device
+    ent_d = torch.empty(2 * B + 4, dtype=torch.float64, device=dev)   # per-entry diffusion losses, then the results
+    ent_f = torch.empty(8 * B, dtype=torch.float32, device=dev)
+    results = ent_d[2 * B:]
+    rc = _lib.load().dg_rec_head_fwd(ui.data_ptr(), out_u.data_ptr(), out_i.data_ptr(), row_loss_u.data_ptr(),
+                                     row_loss_i.data_ptr(), ancs.data_ptr(), poss.data_ptr(), negs.data_ptr(), B, n_user,
+                                     n_item, float(batch_div), float(reg), DG_D, ent_f.data_ptr(), ent_d.data_ptr(),
+                                     results.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_rec_head_fwd")
+    return results, ent_f
+
+
+def rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float, ent_f, g):
+    """Backward of rec_head_fwd; g: fp64[4] upstream gradients.  Returns dense (d_ui, d_out_u, d_out_i,
+    d_row_loss_u, d_row_loss_i), zero outside the batch rows."""
+    n, n_item = ui.shape[0], ui.shape[0] - n_user
+    B = ancs.numel()
+    _vec(g, "upstream gradients", torch.float64, 4)
+    dev = ui.device
+    # one cleared buffer for the five outputs and the per-row tags, every part 16-byte aligned
+    tb = n * DG_D * 4
+    zero = torch.zeros(2 * tb + 16 * n, dtype=torch.uint8, device=dev)
+    d_ui = zero[:tb].view(torch.float32).view(n, DG_D)
+    d_out = zero[tb: 2 * tb].view(torch.float32).view(n, DG_D)
+    d_rl = zero[2 * tb: 2 * tb + 8 * n].view(torch.float64)
+    tags = zero[2 * tb + 8 * n:].view(torch.int32)
+    d_out_u, d_out_i = d_out[:n_user], d_out[n_user:]
+    d_rl_u, d_rl_i = d_rl[:n_user], d_rl[n_user:]
+    scratch = torch.empty(3 * B * DG_D, dtype=torch.float32, device=dev)
+    rc = _lib.load().dg_rec_head_bwd(ui.data_ptr(), out_u.data_ptr(), out_i.data_ptr(), ancs.data_ptr(), poss.data_ptr(),
+                                     negs.data_ptr(), B, n_user, n_item, float(batch_div), float(reg), DG_D, ent_f.data_ptr(),
+                                     g.data_ptr(), scratch.data_ptr(), tags.data_ptr(), d_ui.data_ptr(), d_out_u.data_ptr(),
+                                     d_out_i.data_ptr(), d_rl_u.data_ptr(), d_rl_i.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_rec_head_bwd")
+    return d_ui, d_out_u, d_out_i, d_rl_u, d_rl_i

@@ -264,13 +264,65 @@ int dg_diffusion_loss_fwd(const dg_denoiser *dn, const float *time_bias, int32_t
  * dL/d target, and the four [n][64] tables whose products give the weight gradients:
  *     dW_out = dout_tot^T . hid      db_out = colsum(dout_tot)
  *     dW_in[:, :64] = dpre^T . xn    d time_bias[t] = sum_{i: ts_i = t} dpre[i]
- * (two plain GEMMs and a 200-row scatter the caller runs with its BLAS). */
+ * (dg_denoiser_wgrad computes them). */
 int dg_diffusion_loss_bwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps,
                           const float *target, const float *x_start, const float *noise,
                           const int64_t *ts, const float *sqrt_ac, const float *sqrt_1mac,
                           const double *loss_w, const double *g_row_loss, const float *g_out,
                           int64_t n, int32_t d, float *d_x_start, float *d_target, float *dout_tot,
                           float *hid, float *dpre, float *xn, void *stream);
+
+/* a11: weight gradients of the denoiser from the four tables dg_diffusion_loss_bwd wrote and the
+ * per-row timesteps -- what autograd records for the three nn.Linear layers of Denoise
+ * (DiffGraph-Rec/Model.py:184-191, used at :218-232) under loss.backward() (DiffGraph-Rec/main.py:127):
+ *     d_w_out = dout_tot^T . hid     d_b_out = colsum(dout_tot)
+ *     d_w_in  = [ dpre^T . xn | dpre^T . emb[ts] ]  (64x72)     d_b_in = colsum(dpre)
+ *     d_w_emb, d_b_emb: through emb[t] = emb_layer([cos(t f), sin(t f)])
+ * Outputs are DEVICE arrays in torch's [out][in] layout, overwritten.  Sums run in a fixed order
+ * (same bits on every run).  workspace: DEVICE scratch of dg_denoiser_wgrad_workspace(n_steps)
+ * bytes, 16-byte aligned; ts: int64[n] in [0,n_steps). */
+size_t dg_denoiser_wgrad_workspace(int32_t n_steps);
+int dg_denoiser_wgrad(const dg_denoiser *dn, int32_t n_steps, const int64_t *ts, const float *dout_tot,
+                      const float *hid, const float *dpre, const float *xn, int64_t n, int32_t d,
+                      void *workspace, size_t workspace_bytes, float *d_w_emb, float *d_b_emb,
+                      float *d_w_in, float *d_b_in, float *d_w_out, float *d_b_out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * a10: the loss head of HGDM.cal_loss (DiffGraph-Rec/Model.py:101-111; pairPredict,
+ * DiffGraph-Rec/Utils/Utils.py:4-8), forward and backward.  With, per batch entry b,
+ *     A = ui[ancs_b] + out_u[ancs_b],  P = ui[n_user+poss_b] + out_i[poss_b],  N likewise for negs_b,
+ *     s_b = <A,P> - <A,N>:
+ *     bpr  = -sum_b log(sigmoid(s_b)) / batch_div
+ *     reg  = reg_coef * sum_b (|A|^2 + |P|^2 + |N|^2) / batch_div
+ *     diff = mean_b row_loss_u[ancs_b] + mean_b row_loss_i[poss_b]            (fp64)
+ *     loss = bpr + reg + diff
+ * ui: [n_user+n_item][64] layer sums of the target graph; out_u/out_i: denoised embeddings and
+ * row_loss_u/row_loss_i: fp64 per-row losses from dg_diffusion_loss_fwd; ancs/poss/negs: DEVICE
+ * int64[n_batch] (each in range; not checked on the device).
+ * results: DEVICE fp64[4] = {loss, bpr, reg, diff}.  entries: DEVICE workspace, 8 floats and
+ * 2 doubles per batch entry (float[8*n_batch] then, 8-byte aligned, double[2*n_batch]), kept
+ * for the backward call.
+ * ---------------------------------------------------------------------------------- */
+int dg_rec_head_fwd(const float *ui, const float *out_u, const float *out_i, const double *row_loss_u,
+                    const double *row_loss_i, const int64_t *ancs, const int64_t *poss,
+                    const int64_t *negs, int32_t n_batch, int32_t n_user, int32_t n_item,
+                    double batch_div, double reg_coef, int32_t d, float *entries_f,
+                    double *entries_d, double *results, void *stream);
+
+/* Backward of dg_rec_head_fwd.  g: DEVICE fp64[4] = dL/d{loss,bpr,reg,diff} (what autograd hands
+ * back; usually {1,0,0,0}).  Writes the dense gradient tables d_ui [n_user+n_item][64],
+ * d_out_u [n_user][64], d_out_i [n_item][64], d_row_loss_u fp64[n_user], d_row_loss_i fp64[n_item]:
+ * rows of batch entries get their gradient (entries that name the same row are added in batch
+ * order, so the result does not depend on timing); ALL OTHER ROWS MUST BE ZERO ON ENTRY (the caller
+ * clears the tables).  scratch: DEVICE float[3*n_batch*64], 16-byte aligned like the tables.
+ * row_tags: DEVICE int32[2*(n_user+n_item)], ZERO ON ENTRY (per-row entry counts and first-entry
+ * marks, left dirty). */
+int dg_rec_head_bwd(const float *ui, const float *out_u, const float *out_i, const int64_t *ancs,
+                    const int64_t *poss, const int64_t *negs, int32_t n_batch, int32_t n_user,
+                    int32_t n_item, double batch_div, double reg_coef, int32_t d,
+                    const float *entries_f, const double *g, float *scratch, int32_t *row_tags,
+                    float *d_ui, float *d_out_u, float *d_out_i, double *d_row_loss_u,
+                    double *d_row_loss_i, void *stream);
 
 #ifdef __cplusplus
 }

@@ -254,6 +254,75 @@ def test_rec_cal_loss_values_golden():
     np.testing.assert_allclose([float(v.detach()) for v in vals], fx["cl_losses"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("n", [1, 13, 1000, 40001])
+def test_denoiser_weight_gradients_match_fp64(n):
+    """dg_denoiser_wgrad against the same contractions in fp64 torch (what autograd computes for the three
+    Linear layers of Denoise, DiffGraph-Rec/Model.py:218-232), at ragged sizes; and the same bits twice."""
+    gen = torch.Generator().manual_seed(n)
+    dn = dg.Denoise([64, 64], [64, 64], 8, norm=True).to(DEV)
+    p = dn.params(True)
+    T_ = 200
+    tabs = [torch.randn(n, 64, generator=gen) for _ in range(4)]
+    ts = torch.randint(0, T_, (n,), generator=gen)
+    got = ops.denoiser_wgrad(p, T_, dev(ts), *[dev(t) for t in tabs])
+    got2 = ops.denoiser_wgrad(p, T_, dev(ts), *[dev(t) for t in tabs])
+    dout, hid, dpre, xn = [t.double() for t in tabs]
+    w_emb, b_emb, w_in = (dn.emb_layer.weight.detach().cpu().double(), dn.emb_layer.bias.detach().cpu().double(),
+                          dn.in_layers[0].weight.detach().cpu().double())
+    freqs = torch.exp(-np.log(10000) * torch.arange(0, 4, dtype=torch.float32) / 4)
+    arg = ts[:, None].float() * freqs[None]
+    te = torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1).double()   # Model.py:215-217
+    emb = te @ w_emb.t() + b_emb
+    d_emb = dpre @ w_in[:, 64:]
+    want = (d_emb.t() @ te, d_emb.sum(0), torch.cat([dpre.t() @ xn, dpre.t() @ emb], dim=1), dpre.sum(0),
+            dout.t() @ hid, dout.sum(0))
+    for nm, g, g2, w in zip(("w_emb", "b_emb", "w_in", "b_in", "w_out", "b_out"), got, got2, want):
+        assert torch.equal(g, g2), nm
+        scale = max(float(w.abs().max()), 1.0)
+        np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=0, atol=2e-5 * scale * max(1.0, np.sqrt(n) / 30),
+                                   err_msg="grad " + nm)
+
+
+@pytest.mark.parametrize("n_batch", [1, 37, 2048])
+def test_rec_loss_head_matches_torch_autograd(n_batch):
+    """The fused loss head (values and all five gradients) against the reference's own formulation in torch
+    ops (DiffGraph-Rec/Model.py:101-111), with batch entries that name the same row many times."""
+    from diffgraph_amd.model_rec import _RecHeadFn, pairPredict
+    nu, ni = 50, 70
+    gen = torch.Generator().manual_seed(n_batch)
+    mk = lambda *s: torch.randn(*s, generator=gen)
+    ui, out_u, out_i = mk(nu + ni, 64) * 0.3, mk(nu, 64) * 0.1, mk(ni, 64) * 0.1
+    rl_u, rl_i = torch.rand(nu, generator=gen).double(), torch.rand(ni, generator=gen).double()
+    ancs = torch.randint(0, nu, (n_batch,), generator=gen)
+    poss = torch.randint(0, ni, (n_batch,), generator=gen)
+    negs = torch.randint(0, ni, (n_batch,), generator=gen)
+    wts = torch.tensor([1.0, 0.25, -0.5, 2.0], dtype=torch.float64)
+    batch_div, reg = 2048.0, 3e-2
+
+    leaves = [t.clone().requires_grad_(True) for t in (ui, out_u, out_i, rl_u, rl_i)]
+    u, ou, oi, ru, ri = leaves
+    usr, itm = u[:nu] + ou, u[nu:] + oi
+    a, p, n = usr[ancs], itm[poss], itm[negs]
+    bpr = -(pairPredict(a, p, n)).sigmoid().log().sum() / batch_div
+    regl = ((torch.norm(a) ** 2 + torch.norm(p) ** 2 + torch.norm(n) ** 2) * reg) / batch_div
+    diff = ru[ancs].mean() + ri[poss].mean()
+    want = torch.stack([(bpr + regl + diff).double(), bpr.double(), regl.double(), diff])
+    (want * wts).sum().backward()
+
+    dl = [dev(t).requires_grad_(True) for t in (ui, out_u, out_i, rl_u, rl_i)]
+    got = _RecHeadFn.apply(*dl, dev(ancs), dev(poss), dev(negs), nu, batch_div, reg)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5)
+    (got * dev(wts)).sum().backward()
+    for nm, g, w in zip(("ui", "out_u", "out_i", "row_loss_u", "row_loss_i"), dl, leaves):
+        scale = float(w.grad.abs().max())
+        np.testing.assert_allclose(g.grad.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * scale, err_msg="grad " + nm)
+    # the same bits on every run (fixed summation order over repeated rows)
+    dl2 = [dev(t).requires_grad_(True) for t in (ui, out_u, out_i, rl_u, rl_i)]
+    (_RecHeadFn.apply(*dl2, dev(ancs), dev(poss), dev(negs), nu, batch_div, reg) * dev(wts)).sum().backward()
+    for g, g2 in zip(dl, dl2):
+        assert torch.equal(g.grad, g2.grad)
+
+
 # ------------------------------------------------------------------------------ a3 (DBLP)
 @pytest.mark.parametrize("tag", ["coded", "named"])
 def test_nc_dblp_golden(tag):
