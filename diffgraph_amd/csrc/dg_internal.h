@@ -41,14 +41,21 @@ struct dg_csr {
   int32_t *colidx = nullptr;     // [nnz], ascending inside a row
   float *colscale = nullptr;     // [nnz] degree norm of the gathered node colidx[p]
   int32_t *row_order = nullptr;  // [n]: hub rows, then wave rows, then group rows (each by falling degree)
-  // Group rows, in schedule order, 16 words each: words 0..12 the first 13 neighbour ids
-  // (-1 = none), word 13 the row id, word 14 its degree, word 15 the colidx position of
-  // neighbour 13.  One coalesced 64-B read gives a short row everything it needs.
-  int32_t *head = nullptr;       // [n_group][16]
-  float *head_scale = nullptr;   // [n_group][16] norms of the 13 head neighbours
-  int32_t *wave_desc = nullptr;  // [n_wave][4] row, colidx begin, colidx end, 0
-  int32_t *hub_desc = nullptr;   // [n_hub][4] row, first slab row, last slab row + 1, 0
-  int32_t *seg_desc = nullptr;   // [n_seg][2] colidx begin, end of each hub-row segment
+  // One 16-word record per node of [slot_begin, slot_begin + n_slots), in node order: words 0..12 the first 13 neighbour ids (-1 = none),
+  // word 13 the row id, word 14 its degree -- or -1 when the row is not a group row (summed as a
+  // wave or hub row, or not owned by this rank) -- word 15 the colidx position of neighbour 13.
+  // One coalesced 64-B read gives a short row everything it needs.
+  int32_t *head = nullptr;       // [n_slots][16]
+  float *head_scale = nullptr;   // [n_slots][16] norms of the 13 head neighbours
+  int32_t n_slots = 0, slot_begin = 0;  // all nodes, or the span of the rows this rank owns (none for LDS-split graphs)
+  int32_t *wave_desc = nullptr;  // unused (kept for layout compatibility of the export selectors)
+  int32_t *hub_desc = nullptr;   // [n_hub][4] cut row, first slab row, last slab row + 1, 0
+  // Pieces of cut rows, in the order the workgroups take them (see build_schedule for the XCD-aware
+  // order); a slot is {colidx begin, end, slab row (-1: empty slot), 0}.  seg_desc: pieces summed by a
+  // wavefront, four per block; gseg_desc: short pieces summed by a 16-lane group, sixteen per block.
+  int32_t *seg_desc = nullptr;   // [n_seg_slots][4]
+  int32_t *gseg_desc = nullptr;  // [n_gseg_slots][4]
+  int32_t n_seg_slots = 0, n_gseg_slots = 0;
   int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0;
   // Bipartite graphs whose second block is small enough for LDS (Industry shape: 1M users x 361
   // items): rows [0, lds_split) gather only from rows [lds_split, n), whose table (<= 96 KB)
@@ -87,7 +94,7 @@ struct dg_graph {
 struct dg_task_dev {
   const int32_t *rowptr;
   const uint32_t *lhead;
-  const int32_t *colidx, *head, *wave_desc, *hub_desc, *seg_desc;
+  const int32_t *colidx, *head, *hub_desc, *seg_desc, *gseg_desc;
   const float *colscale, *head_scale;
   const float *dinv_row;     // norm of the receiving (row) node
   const float *dinv_out;     // norm applied by DG_OUT_PRESCALE (the row node's norm as a future source)
@@ -101,7 +108,9 @@ struct dg_task_dev {
   const float *e_saved;  // backward: saved forward activation of this layer (NULL: layer 0)
   const float *d_sum;    // backward: gradient wrt the layer sum
   float *row_norm;       // forward: ||y|| out (NULL: off); backward with DG_BWD_NORM_FEED: ||y|| in
-  int32_t n, n_hub, n_wave, n_group, n_seg;
+  int32_t n, n_hub, n_wave, n_group, n_seg;  // n_group: head records (dg_csr::n_slots)
+  int32_t n_seg_slots, n_gseg_slots;
+  int32_t group_row0;                        // node of head record 0
   int32_t flags;
   float slope;
   int32_t lds_split;      // > 0: rows below it are summed by lds_rows_kernel

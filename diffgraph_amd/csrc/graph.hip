@@ -31,13 +31,14 @@ extern "C" int dg_version(void) { return 1; }
 namespace {
 
 constexpr int kHead = 13;  // neighbour ids carried in a group row's 16-word head
+constexpr int kGroupPiece = 32;  // pieces of cut rows up to this long are summed by one 16-lane group, longer ones by a wavefront
 
 struct HostCsr {
-  std::vector<int32_t> rowptr, colidx, row_order, head, wave_desc, hub_desc, seg_desc;
+  std::vector<int32_t> rowptr, colidx, row_order, head, wave_desc, hub_desc, seg_desc, gseg_desc;
   std::vector<float> colscale, head_scale;
   std::vector<uint32_t> lhead, wblocks, woff;
   std::vector<int32_t> witems;
-  int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0, lds_split = 0, n_windows = 0, n_parts = 0;
+  int32_t n_hub = 0, n_wave = 0, n_group = 0, n_seg = 0, lds_split = 0, n_windows = 0, n_parts = 0, n_slots = 0, slot_begin = 0, n_seg_slots = 0, n_gseg_slots = 0;
 };
 
 // CSR over `row` with ascending `col` inside each row: two stable counting sorts
@@ -183,9 +184,10 @@ bool build_windows(int32_t n, const std::vector<int32_t> &deg, HostCsr &c) {
   return true;
 }
 
-// Rows ordered hub | wave | group, each class by falling degree (ties: rising row id), so
-// the longest work starts first and the four rows sharing a wavefront have like lengths.
-// Rows below c.lds_split (if set) are left to lds_rows_kernel and appear in no class.
+// Two row classes: group rows (in-degree <= group_max: summed whole by one 16-lane group, in node
+// order) and cut rows (longer: summed in pieces through the slab).  row_order lists cut rows, then
+// group rows, each by falling degree.  Rows below c.lds_split (if set) are left to lds_rows_kernel
+// and appear in no class.
 void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c, const std::vector<char> *owned = nullptr) {
   std::vector<int32_t> deg(n);
   for (int32_t i = 0; i < n; ++i) deg[i] = c.rowptr[i + 1] - c.rowptr[i];
@@ -218,49 +220,107 @@ void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c, c
       for (int32_t k = 0; k < std::min(deg[r], 31); ++k) hw[k + 1] = (uint16_t)(c.colidx[c.rowptr[r] + k] - c.lds_split);
       for (int k = 0; k < 16; ++k) c.lhead[(size_t)r * 16 + k] = (uint32_t)hw[2 * k] | ((uint32_t)hw[2 * k + 1] << 16);
     }
-    c.n_hub = n - c.lds_split; c.n_wave = c.n_group = c.n_seg = 0;
-    c.seg_desc.clear(); c.wave_desc.clear(); c.head.clear(); c.head_scale.clear();
+    c.n_hub = n - c.lds_split; c.n_wave = c.n_group = c.n_seg = c.n_slots = c.slot_begin = c.n_seg_slots = c.n_gseg_slots = 0;
+    c.seg_desc.clear(); c.gseg_desc.clear(); c.wave_desc.clear(); c.head.clear(); c.head_scale.clear();
     return;
   }
   std::stable_sort(c.row_order.begin(), c.row_order.end(),
                    [&](int32_t a, int32_t b) { return deg[a] > deg[b]; });
-  n = (int32_t)c.row_order.size();  // rows scheduled in the three classes
+  n = (int32_t)c.row_order.size();  // rows scheduled in the two classes
   c.n_hub = c.n_wave = c.n_group = 0;
   for (int32_t k = 0; k < n; ++k) {
-    int32_t d = deg[c.row_order[k]];
-    if (d > seg_len) c.n_hub++;
-    else if (d > group_max) c.n_wave++;
+    if (deg[c.row_order[k]] > group_max) c.n_hub++;
     else c.n_group++;
   }
-  c.hub_desc.clear(); c.seg_desc.clear(); c.wave_desc.clear();
+  // Cut rows.  The node ids are split into 8 ranges holding equal shares of the cut rows' neighbours;
+  // a cut row's (ascending) neighbour list is cut at the range limits, and pieces longer than seg_len
+  // again into equal parts.  Range x is summed by the workgroups whose index is x (mod 8) -- blocks
+  // b, b + 8, ... share an XCD -- so each XCD keeps gathering from the same eighth of the source table
+  // and finds it in its L2.  Every piece writes one slab row; a row's slab rows are consecutive, in
+  // ascending neighbour order.
+  c.hub_desc.clear(); c.seg_desc.clear(); c.gseg_desc.clear(); c.wave_desc.clear();
   c.n_seg = 0;
+  constexpr int kRuns = 8;
+  int32_t limit[kRuns + 1];
+  {
+    std::vector<int32_t> ids;
+    for (int32_t h = 0; h < c.n_hub; ++h) {
+      const int32_t r = c.row_order[h];
+      ids.insert(ids.end(), c.colidx.begin() + c.rowptr[r], c.colidx.begin() + c.rowptr[r + 1]);
+    }
+    limit[0] = 0;
+    limit[kRuns] = INT32_MAX;
+    for (int x = 1; x < kRuns; ++x) {
+      if (ids.empty()) { limit[x] = INT32_MAX; continue; }
+      const size_t q = ids.size() * (size_t)x / kRuns;
+      std::nth_element(ids.begin(), ids.begin() + q, ids.end());
+      limit[x] = ids[q];
+    }
+  }
+  struct Piece { int32_t begin, end, slab; };
+  std::vector<Piece> wave_pieces[kRuns], group_pieces[kRuns];
   for (int32_t h = 0; h < c.n_hub; ++h) {
-    int32_t r = c.row_order[h];
-    int32_t b = c.rowptr[r], e = c.rowptr[r + 1];
-    int32_t s0 = c.n_seg;
-    for (int32_t p = b; p < e; p += seg_len) {
-      c.seg_desc.push_back(p);
-      c.seg_desc.push_back(std::min(p + seg_len, e));
-      c.n_seg++;
+    const int32_t r = c.row_order[h];
+    const int32_t *col = c.colidx.data();
+    const int32_t s0 = c.n_seg;
+    int32_t p = c.rowptr[r];
+    const int32_t e = c.rowptr[r + 1];
+    for (int x = 0; x < kRuns && p < e; ++x) {
+      const int32_t pe = x + 1 == kRuns ? e : (int32_t)(std::lower_bound(col + p, col + e, limit[x + 1]) - col);
+      const int32_t len = pe - p;
+      if (len <= 0) continue;
+      const int32_t parts = (len + seg_len - 1) / seg_len;
+      for (int32_t k = 0; k < parts; ++k) {
+        const int32_t b0 = p + (int32_t)((int64_t)len * k / parts), b1 = p + (int32_t)((int64_t)len * (k + 1) / parts);
+        (b1 - b0 > kGroupPiece ? wave_pieces : group_pieces)[x].push_back({b0, b1, c.n_seg++});
+      }
+      p = pe;
     }
     c.hub_desc.insert(c.hub_desc.end(), {r, s0, c.n_seg, 0});
   }
-  for (int32_t k = 0; k < c.n_wave; ++k) {
-    int32_t r = c.row_order[c.n_hub + k];
-    c.wave_desc.insert(c.wave_desc.end(), {r, c.rowptr[r], c.rowptr[r + 1], 0});
+  // slot tables: run x's pieces go to blocks x, x + 8, x + 16, ... of the class, `per_block` pieces each
+  auto lay_out = [&](std::vector<Piece> (&runs)[kRuns], int per_block, std::vector<int32_t> &desc, int32_t &n_slots) {
+    size_t longest = 0;
+    for (int x = 0; x < kRuns; ++x) longest = std::max(longest, runs[x].size());
+    const int32_t blocks_per_run = (int32_t)((longest + per_block - 1) / per_block);
+    n_slots = blocks_per_run * kRuns * per_block;
+    desc.assign((size_t)n_slots * 4, 0);
+    for (int32_t slot = 0; slot < n_slots; ++slot) desc[(size_t)slot * 4 + 2] = -1;
+    for (int x = 0; x < kRuns; ++x)
+      for (size_t i = 0; i < runs[x].size(); ++i) {
+        const size_t slot = ((i / per_block) * kRuns + x) * per_block + i % per_block;
+        desc[slot * 4 + 0] = runs[x][i].begin;
+        desc[slot * 4 + 1] = runs[x][i].end;
+        desc[slot * 4 + 2] = runs[x][i].slab;
+      }
+  };
+  lay_out(wave_pieces, 4, c.seg_desc, c.n_seg_slots);
+  lay_out(group_pieces, 16, c.gseg_desc, c.n_gseg_slots);
+  // One head record per node, in node order (rows of the other classes, and rows this rank does not own,
+  // carry degree -1 and are skipped): a group then knows its row before the record arrives, and the
+  // epilogue's tables are read and written as consecutive lines.
+  // The records span the owned rows only (a rank of a row-block partition owns one block).
+  const int32_t n_nodes = (int32_t)deg.size();
+  int32_t lo = 0, hi = n_nodes;
+  if (owned) {
+    while (lo < hi && !(*owned)[lo]) ++lo;
+    while (hi > lo && !(*owned)[hi - 1]) --hi;
   }
-  c.head.assign((size_t)c.n_group * 16, -1);
-  c.head_scale.assign((size_t)c.n_group * 16, 0.f);
-  for (int32_t k = 0; k < c.n_group; ++k) {
-    int32_t r = c.row_order[c.n_hub + c.n_wave + k];
-    int32_t b = c.rowptr[r], d = c.rowptr[r + 1] - b;
-    int32_t *hd = &c.head[(size_t)k * 16];
-    float *hs = &c.head_scale[(size_t)k * 16];
+  c.slot_begin = lo;
+  c.n_slots = hi - lo;
+  c.head.assign((size_t)c.n_slots * 16, -1);
+  c.head_scale.assign((size_t)c.n_slots * 16, 0.f);
+  for (int32_t r = lo; r < hi; ++r) {
+    int32_t *hd = &c.head[(size_t)(r - lo) * 16];
+    hd[13] = r;
+    if ((owned && !(*owned)[r]) || deg[r] > group_max) continue;  // hd[14] stays -1
+    float *hs = &c.head_scale[(size_t)(r - lo) * 16];
+    const int32_t b = c.rowptr[r], d = deg[r];
     for (int32_t j = 0; j < std::min(d, kHead); ++j) {
       hd[j] = c.colidx[b + j];
       hs[j] = c.colscale[b + j];
     }
-    hd[13] = r; hd[14] = d; hd[15] = b + kHead;
+    hd[14] = d; hd[15] = b + kHead;
   }
 }
 
@@ -285,20 +345,21 @@ hipError_t upload_csr(const HostCsr &h, dg_csr &d) {
   if ((e = upload(h.wave_desc, &d.wave_desc)) != hipSuccess) return e;
   if ((e = upload(h.hub_desc, &d.hub_desc)) != hipSuccess) return e;
   if ((e = upload(h.seg_desc, &d.seg_desc)) != hipSuccess) return e;
+  if ((e = upload(h.gseg_desc, &d.gseg_desc)) != hipSuccess) return e;
   if ((e = upload(h.lhead, &d.lhead)) != hipSuccess) return e;
   if ((e = upload(h.wblocks, &d.wblocks)) != hipSuccess) return e;
   if ((e = upload(h.woff, &d.woff)) != hipSuccess) return e;
   if ((e = upload(h.witems, &d.witems)) != hipSuccess) return e;
   d.n_windows = h.n_windows; d.n_parts = h.n_parts;
   d.n_hub = h.n_hub; d.n_wave = h.n_wave; d.n_group = h.n_group; d.n_seg = h.n_seg;
-  d.lds_split = h.lds_split;
+  d.lds_split = h.lds_split; d.n_slots = h.n_slots; d.slot_begin = h.slot_begin; d.n_seg_slots = h.n_seg_slots; d.n_gseg_slots = h.n_gseg_slots;
   return hipSuccess;
 }
 
 void free_csr(dg_csr &d) {
   (void)hipFree(d.rowptr); (void)hipFree(d.colidx); (void)hipFree(d.colscale); (void)hipFree(d.row_order);
   (void)hipFree(d.head); (void)hipFree(d.head_scale); (void)hipFree(d.wave_desc); (void)hipFree(d.hub_desc);
-  (void)hipFree(d.seg_desc); (void)hipFree(d.lhead);
+  (void)hipFree(d.seg_desc); (void)hipFree(d.gseg_desc); (void)hipFree(d.lhead);
   (void)hipFree(d.wblocks); (void)hipFree(d.woff); (void)hipFree(d.witems);
   d = dg_csr();
 }
@@ -322,7 +383,7 @@ extern "C" int dg_graph_create_ex(int32_t n, int64_t nnz, const int32_t *src, co
     return dg_fail(DG_ERR_SIZE, "dg_graph_create: %lld edges exceed the int32 CSR limit", (long long)nnz);
   if ((int64_t)n * DG_D * 4 >= ((int64_t)1 << 32))
     return dg_fail(DG_ERR_SIZE, "dg_graph_create: %d nodes exceed the 4 GiB table limit of the gather path", n);
-  if (group_max <= 0) group_max = 32;
+  if (group_max <= 0) group_max = 64;
   if (seg_len <= 0) seg_len = 256;
   if (seg_len < 64 || seg_len % 64 != 0)
     return dg_fail(DG_ERR_ARG, "dg_graph_create: seg_len must be a positive multiple of 64 (got %d)", seg_len);

@@ -11,12 +11,14 @@
 // neighbour rows (1 KiB, four fully used 256-B segments).  A group reads 16 neighbour ids
 // with one coalesced load, then hands them round with DPP row broadcasts (no LDS).  Rows
 // are binned by in-degree on the host:
-//   group rows (deg <= group_max): one group per row, four rows per wavefront;
-//   wave rows  (deg <= seg_len)  : the four groups of a wavefront take every fourth chunk
-//                                  of 16 neighbours, then add their sums;
-//   hub rows   (deg >  seg_len)  : cut into seg_len-neighbour segments summed by separate
-//                                  wavefronts of the same launch into a slab; a second,
-//                                  small launch adds each hub row's slab rows in order.
+//   group rows (deg <= group_max): one group per row, four rows per wavefront, in node order
+//                                  (consecutive rows stream through the epilogue as whole lines);
+//   cut rows   (deg >  group_max): the neighbour list is cut by source-node range (8 ranges, one
+//                                  per XCD, so that each XCD's L2 serves one eighth of the source
+//                                  table) and into pieces of <= seg_len neighbours; a piece is
+//                                  summed by a wavefront (four groups take every fourth chunk of
+//                                  16 neighbours) or, when short, by one group, into a slab row;
+//                                  a second, small launch adds each cut row's slab rows in order.
 // A group row's first 13 neighbour ids, its row id and degree sit in one 64-B head record
 // (graph.hip), and every edge carries the gathered node's degree norm next to its id, so
 // the dependent-load chain of a short row is: head -> neighbour rows -> store.
@@ -51,6 +53,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const float *base, 
 __device__ __forceinline__ f32x4 load_row16(__amdgpu_buffer_rsrc_t r, int row, unsigned lane_off) {
   unsigned off = (unsigned)row * (unsigned)(DG_D * 4) + lane_off;  // row == -1 -> out of range -> zeros
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// Tables the epilogue streams through once (running sums, stored activations).  Plain accesses: the
+// non-temporal hint made the layer 2-7 % slower on the Tmall-shaped graphs.
+__device__ __forceinline__ f32x4 load_stream(const float *base, size_t o4) {
+  return reinterpret_cast<const f32x4 *>(base)[o4];
+}
+__device__ __forceinline__ void store_stream(float *base, size_t o4, f32x4 v) {
+  reinterpret_cast<f32x4 *>(base)[o4] = v;
 }
 
 // Four neighbours K0..K0+3 of the current chunk: issue the four row loads, then add.
@@ -150,8 +161,8 @@ __device__ __forceinline__ row_ctx load_row_ctx(const dg_task_dev &T, int row, i
   if (s_src) c.sc = s_src[row];  // one load instruction for the three per-row scalars
   c.a_in = f32x4{0.f, 0.f, 0.f, 0.f};
   c.g_in = c.a_in;
-  if (a_src) c.a_in = reinterpret_cast<const f32x4 *>(a_src)[o];
-  if (g_src) c.g_in = reinterpret_cast<const f32x4 *>(g_src)[o];
+  if (a_src) c.a_in = load_stream(a_src, o);
+  if (g_src) c.g_in = load_stream(g_src, o);
   return c;
 }
 
@@ -161,7 +172,7 @@ __device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, cons
   const float di = bcast16f<0>(rc.sc), dsrc = bcast16f<1>(rc.sc), rn = bcast16f<2>(rc.sc);
   f32x4 G = acc * di;
   if (!T.e_saved) {
-    reinterpret_cast<f32x4 *>(T.e_out)[o] = G;
+    store_stream(T.e_out, o, G);
     return;
   }
   const f32x4 e = rc.a_in, g = rc.g_in;
@@ -186,7 +197,7 @@ __device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, cons
   dz.y = e.y > 0.f ? dE.y : dE.y * slope;
   dz.z = e.z > 0.f ? dE.z : dE.z * slope;
   dz.w = e.w > 0.f ? dE.w : dE.w * slope;
-  reinterpret_cast<f32x4 *>(T.e_out)[o] = dz * dsrc;
+  store_stream(T.e_out, o, dz * dsrc);
 }
 
 // rst*norm, LeakyReLU, F.normalize, layer sum, next layer's input (Model.py:165-172,67-70).
@@ -218,57 +229,56 @@ __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const ro
       const float ps = sum16(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w);
       a += p * fminf(__builtin_amdgcn_rsqf(ps), 1e12f * __builtin_amdgcn_rcpf(dsrc));
     }
-    reinterpret_cast<f32x4 *>(T.acc_out)[o] = a + yn;
+    store_stream(T.acc_out, o, a + yn);
   }
   if (T.e_out) {
     f32x4 e = (T.flags & DG_OUT_NORM) ? yn : y;
     if (T.flags & DG_OUT_PRESCALE) e *= dsrc;
-    reinterpret_cast<f32x4 *>(T.e_out)[o] = e;
+    store_stream(T.e_out, o, e);
   }
 }
 
-// Blocks of one task, longest work first: hub-row segments (one wavefront each, partial
-// sums into the slab), wave rows, group rows.
+// Blocks of one task, longest work first: long pieces of cut rows (one wavefront each, partial
+// sums into the slab), short pieces (one group each), group rows.
 template <bool SCALE>
 __device__ __forceinline__ void layer_block(const dg_task_dev &T, int lb) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l = lane & 15;
-  const int nb_seg = (T.n_seg + 3) >> 2, nb_wave = (T.n_wave + 3) >> 2;
+  const int nb_seg = T.n_seg_slots >> 2, nb_gseg = T.n_gseg_slots >> 4;
   const __amdgpu_buffer_rsrc_t xr = table_rsrc(T.x, T.n);
   if (lb < nb_seg) {
-    const int s = lb * 4 + wave;
-    if (s < T.n_seg) {
-      const int p = T.seg_desc[2 * s], e = T.seg_desc[2 * s + 1];
+    const int4 d = reinterpret_cast<const int4 *>(T.seg_desc)[lb * 4 + wave];  // begin, end, slab row
+    if (d.z >= 0) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      gather_rows<true, SCALE>(xr, T.colidx, T.colscale, p + 16 * q, e, 64, l, acc);
+      gather_rows<true, SCALE>(xr, T.colidx, T.colscale, d.x + 16 * q, d.y, 64, l, acc);
       acc = add_groups(acc);
-      if (q == 0) reinterpret_cast<f32x4 *>(T.slab)[(size_t)s * (DG_D / 4) + l] = acc;
+      if (q == 0) reinterpret_cast<f32x4 *>(T.slab)[(size_t)d.z * (DG_D / 4) + l] = acc;
     }
-  } else if (lb < nb_seg + nb_wave) {
-    const int k = (lb - nb_seg) * 4 + wave;
-    if (k < T.n_wave) {
-      const int4 d = reinterpret_cast<const int4 *>(T.wave_desc)[k];
-      const row_ctx rc = load_row_ctx(T, d.x, l);
+  } else if (lb < nb_seg + nb_gseg) {
+    const int4 d = reinterpret_cast<const int4 *>(T.gseg_desc)[(lb - nb_seg) * 16 + wave * 4 + q];
+    if (d.z >= 0) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      gather_rows<true, SCALE>(xr, T.colidx, T.colscale, d.y + 16 * q, d.z, 64, l, acc);
-      acc = add_groups(acc);
-      if (q == 0) epilogue(T, d.x, rc, acc, l);
+      gather_rows<true, SCALE>(xr, T.colidx, T.colscale, d.x, d.y, 16, l, acc);
+      reinterpret_cast<f32x4 *>(T.slab)[(size_t)d.z * (DG_D / 4) + l] = acc;
     }
   } else {
-    const int k = (lb - nb_seg - nb_wave) * 16 + wave * 4 + q;
+    // group rows: slot k IS node k, so the epilogue's inputs are asked for together with the head record
+    const int k = (lb - nb_seg - nb_gseg) * 16 + wave * 4 + q, row = T.group_row0 + k;
     if (k < T.n_group) {
       const int hv = T.head[(size_t)k * 16 + l];
       const float hs = SCALE ? T.head_scale[(size_t)k * 16 + l] : 0.f;
-      const int row = bcast16<13>(hv), deg = bcast16<14>(hv), tail = bcast16<15>(hv);
       const row_ctx rc = load_row_ctx(T, row, l);
-      const int c = l < 13 ? hv : -1;
-      const unsigned lane_off = (unsigned)l * 16u;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      gather4<0, SCALE>(xr, c, hs, lane_off, acc);
-      if (deg > 4) gather4<4, SCALE>(xr, c, hs, lane_off, acc);
-      if (deg > 8) gather4<8, SCALE>(xr, c, hs, lane_off, acc);
-      if (deg > 12) gather4<12, SCALE>(xr, c, hs, lane_off, acc);
-      if (deg > 13) gather_rows<true, SCALE>(xr, T.colidx, T.colscale, tail, tail + deg - 13, 16, l, acc);
-      epilogue(T, row, rc, acc, l);
+      const int deg = bcast16<14>(hv), tail = bcast16<15>(hv);
+      if (deg >= 0) {
+        const int c = l < 13 ? hv : -1;
+        const unsigned lane_off = (unsigned)l * 16u;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        gather4<0, SCALE>(xr, c, hs, lane_off, acc);
+        if (deg > 4) gather4<4, SCALE>(xr, c, hs, lane_off, acc);
+        if (deg > 8) gather4<8, SCALE>(xr, c, hs, lane_off, acc);
+        if (deg > 12) gather4<12, SCALE>(xr, c, hs, lane_off, acc);
+        if (deg > 13) gather_rows<true, SCALE>(xr, T.colidx, T.colscale, tail, tail + deg - 13, 16, l, acc);
+        epilogue(T, row, rc, acc, l);
+      }
     }
   }
 }
@@ -564,12 +574,12 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   o.dinv_gather = transpose ? g->dinv_dst : g->dinv_src;
   o.wblocks = c.wblocks; o.woff = c.woff; o.witems = c.witems; o.n_windows = c.n_windows; o.n_parts = c.n_parts;
   o.win_blk_begin = 0; o.win_blk_count = 0;
-  o.colidx = c.colidx; o.head = c.head; o.wave_desc = c.wave_desc; o.hub_desc = c.hub_desc; o.seg_desc = c.seg_desc;
+  o.colidx = c.colidx; o.head = c.head; o.hub_desc = c.hub_desc; o.seg_desc = c.seg_desc; o.gseg_desc = c.gseg_desc;
   o.colscale = c.colscale; o.head_scale = c.head_scale;
   o.dinv_row = transpose ? g->dinv_src : g->dinv_dst;
   o.dinv_out = transpose ? g->dinv_dst : g->dinv_src;
   o.x = in.x; o.slab = g->slab; o.e_out = in.e_out; o.acc_in = in.acc_in; o.acc_out = in.acc_out;
-  o.n = g->n; o.n_hub = c.n_hub; o.n_wave = c.n_wave; o.n_group = c.n_group; o.n_seg = c.n_seg;
+  o.n = g->n; o.n_hub = c.n_hub; o.n_wave = c.n_wave; o.n_group = c.n_slots; o.group_row0 = c.slot_begin; o.n_seg = c.n_seg; o.n_seg_slots = c.n_seg_slots; o.n_gseg_slots = c.n_gseg_slots;
   o.flags = in.flags; o.slope = in.slope;
   o.e_saved = nullptr; o.d_sum = nullptr;
   o.fin_partials = nullptr; o.fin_stride = 0; o.fin_parts = o.fin_row_begin = o.fin_rows = 0;
@@ -586,9 +596,10 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
       if (graphs[j] == graphs[k] && batch.t[k].n_seg > 0)
         return dg_fail(DG_ERR_ARG, "layer tasks %d and %d share a graph with hub rows (one slab per graph)", j, k);
     dg_task_dev &t = batch.t[k];
+    blocks = (blocks + 7) & ~7;  // a task's block b and blockIdx.x agree mod 8 (the segment order counts on it)
     t.blk_begin = blocks;
     t.hub_blk_begin = hub_blocks;
-    blocks += ((t.n_seg + 3) >> 2) + ((t.n_wave + 3) >> 2) + ((t.n_group + 15) >> 4);
+    blocks += (t.n_seg_slots >> 2) + (t.n_gseg_slots >> 4) + ((t.n_group + 15) >> 4);
     hub_blocks += t.lds_split > 0 ? t.n_hub : (t.n_hub + 3) >> 2;
   }
   // workgroups of the two LDS kernels: one per CU in total each, shared out by the tasks' work
