@@ -18,7 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kMaxBatch = 1 << 20;
+constexpr int kMaxBatch = 8192;  // the three index lists of a batch sit in LDS as int32: 96 KiB at most
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
@@ -128,28 +128,41 @@ __global__ __launch_bounds__(256) void head_bwd_entries_kernel(const float *ui, 
 
 // Entry e of the user list or of the item list writes its row of the gradient tables when it is
 // the only entry naming that row; when several do, the first of them adds the later ones in list
-// order (found by scanning the list) and the others leave.
+// order and the others leave.  A workgroup with such a first entry copies the lists into LDS once
+// (as int32) and the entry's group scans its list there, 16 entries per step.
 __global__ __launch_bounds__(256) void head_scatter_kernel(const int64_t *ancs, const int64_t *poss, const int64_t *negs,
                                                            int n_batch, int n_user, const double *g, const float *scratch,
                                                            const int *tag, const int *cnt, float *d_ui, float *d_out_u,
                                                            float *d_out_i, double *d_rl_u, double *d_rl_i) {
+  extern __shared__ int idx[];  // [3 * n_batch]: ancs | poss | negs
   const int e_all = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15, q = (threadIdx.x & 63) >> 4;
-  if (e_all >= 3 * n_batch) return;
+  const bool valid = e_all < 3 * n_batch;
   const bool user = e_all < n_batch;
   const int e = user ? e_all : e_all - n_batch, m = user ? n_batch : 2 * n_batch;
-  const int64_t *list0 = user ? ancs : poss;            // list entry j: j < n_batch ? list0[j] : negs[j - n_batch]
-  const int row = (int)(e < n_batch ? list0[e] : negs[e - n_batch]);
-  const int trow = user ? row : n_user + row;
-  const int c = cnt[trow];
-  if (c > 1 && m - tag[trow] != e) return;  // an earlier entry owns this row (the whole group leaves)
+  int row = 0, trow = 0, c = 0;
+  bool owner = false;
+  if (valid) {
+    row = (int)(user ? ancs[e] : (e < n_batch ? poss[e] : negs[e - n_batch]));
+    trow = user ? row : n_user + row;
+    c = cnt[trow];
+    owner = c == 1 || m - tag[trow] == e;  // the only entry naming this row, or the first of several
+  }
+  const bool scan = owner && c > 1;
+  if (__syncthreads_or(scan)) {
+    for (int i = threadIdx.x; i < 3 * n_batch; i += 256)
+      idx[i] = (int)(i < n_batch ? ancs[i] : (i < 2 * n_batch ? poss[i - n_batch] : negs[i - 2 * n_batch]));
+    __syncthreads();
+  }
+  if (!owner) return;  // (whole groups leave)
   const f32x4 *G = reinterpret_cast<const f32x4 *>(scratch) + (user ? (size_t)0 : (size_t)n_batch * 16);
   f32x4 acc = G[(size_t)e * 16 + l];
   int n_loss = user || e < n_batch ? 1 : 0;  // entries that carry a diffusion-loss row: ancs, poss
-  if (c > 1) {
+  if (scan) {
+    const int *list = user ? idx : idx + n_batch;
     int left = c - 1;
     for (int j0 = (e + 1) & ~15; left > 0 && j0 < m; j0 += 16) {
       const int j = j0 + l;
-      const bool hit = j > e && j < m && (int)(j < n_batch ? list0[j] : negs[j - n_batch]) == row;
+      const bool hit = j > e && j < m && list[j] == row;
       unsigned mask = (unsigned)(__ballot(hit) >> (16 * q)) & 0xffffu;
       while (mask) {
         const int jj = j0 + __builtin_ctz(mask);
@@ -207,7 +220,14 @@ extern "C" int dg_rec_head_bwd(const float *ui, const float *out_u, const float 
   int *tag = row_tags, *cnt = row_tags + n_rows;
   hipLaunchKernelGGL(head_bwd_entries_kernel, dim3((n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ui, out_u, out_i,
                      ancs, poss, negs, n_batch, n_user, n_rows, batch_div, reg_coef, entries_f, g, scratch, tag, cnt);
-  hipLaunchKernelGGL(head_scatter_kernel, dim3((3 * n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ancs, poss, negs,
+  static bool attr_set = false;  // more than 64 KiB of dynamic LDS has to be opted into once
+  if (!attr_set) {
+    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               3 * kMaxBatch * (int)sizeof(int)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(head_scatter_kernel, dim3((3 * n_batch + 15) / 16), dim3(256), 3 * (size_t)n_batch * sizeof(int),
+                     (hipStream_t)stream, ancs, poss, negs,
                      n_batch, n_user, g, scratch, tag, cnt, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
   DG_HIP(hipGetLastError());
   return 0;

@@ -189,13 +189,18 @@ struct fin_args {
   float *mk;  // [64][8] dpre^T . te[ts], for wgrad_emb_kernel
 };
 
-// One thread per float of a partial result: adds the kGroups partials in order and writes the
-// float where it belongs.
+// A workgroup finishes 32 floats of the result: thread (slice, f) adds 1/8 of the kGroups partials of
+// float f in order, then the eight slice sums are added in slice order -- a fixed order overall.
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const fin_args a) {
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= kPartFloats) return;
+  __shared__ float part[8][32];
+  const int slice = threadIdx.x >> 5, f = blockIdx.x * 32 + (threadIdx.x & 31);
   float s = 0.f;
-  for (int g = 0; g < kGroups; ++g) s += a.partials[(size_t)g * kPartFloats + f];
+  if (f < kPartFloats)
+    for (int g = slice * (kGroups / 8); g < (slice + 1) * (kGroups / 8); ++g) s += a.partials[(size_t)g * kPartFloats + f];
+  part[slice][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (slice != 0 || f >= kPartFloats) return;
+  for (int k = 1; k < 8; ++k) s += part[k][threadIdx.x];
   if (f < kPartWin) a.d_w_out[f] = s;
   else if (f < kPartTab) {
     const int o = (f - kPartWin) >> 6, i = (f - kPartWin) & 63;
@@ -263,7 +268,7 @@ extern "C" int dg_denoiser_wgrad(const dg_denoiser *dn, int32_t n_steps, const i
   hipLaunchKernelGGL(wgrad_partial_kernel, dim3(kGroups), dim3(512), 0, s, a);
   fin_args f;
   f.partials = partials; f.d_w_in = d_w_in; f.d_b_in = d_b_in; f.d_w_out = d_w_out; f.d_b_out = d_b_out; f.mk = mk;
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((kPartFloats + 255) / 256), dim3(256), 0, s, f);
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((kPartFloats + 31) / 32), dim3(256), 0, s, f);
   hipLaunchKernelGGL(wgrad_emb_kernel, dim3(1), dim3(128), 0, s, dn->w_in, mk, d_b_in, d_w_emb, d_b_emb);
   DG_HIP(hipGetLastError());
   return 0;

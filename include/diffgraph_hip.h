@@ -298,7 +298,7 @@ int dg_denoiser_wgrad(const dg_denoiser *dn, int32_t n_steps, const int64_t *ts,
  *     loss = bpr + reg + diff
  * ui: [n_user+n_item][64] layer sums of the target graph; out_u/out_i: denoised embeddings and
  * row_loss_u/row_loss_i: fp64 per-row losses from dg_diffusion_loss_fwd; ancs/poss/negs: DEVICE
- * int64[n_batch] (each in range; not checked on the device).
+ * int64[n_batch] (each in range; not checked on the device).  n_batch <= 8192.
  * results: DEVICE fp64[4] = {loss, bpr, reg, diff}.  entries: DEVICE workspace, 8 floats and
  * 2 doubles per batch entry (float[8*n_batch] then, 8-byte aligned, double[2*n_batch]), kept
  * for the backward call.
