@@ -91,6 +91,10 @@ SIGNATURES = {
     "dg_denoiser_wgrad_workspace": (C.c_size_t, [C.c_int32]),
     "dg_denoiser_wgrad": (C.c_int, [C.POINTER(Denoiser), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_size_t] + [C.c_void_p] * 7),
+    "dg_eval_topk_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "dg_eval_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                               C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dg_eval_metrics": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
     "dg_rec_head_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 4),
     "dg_rec_head_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 10),
 }

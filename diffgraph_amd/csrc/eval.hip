@@ -1,0 +1,277 @@
+// All-rank evaluation for gfx950: scores of every test user against every item, training
+// interactions masked out, top-k per user, Recall@k / NDCG@k.
+//
+// Replaces the evaluation loop of Coach.testEpoch (DiffGraph-Rec/main.py:153-160): per batch of
+// 1024 users a dense [1024, n_item] train-mask built on the host row by row
+// (AllRankTestData.__getitem__, DiffGraph-Rec/DataHandler.py:268-272), t.mm(usr, item^T) *
+// (1 - mask) - mask * 1e8, t.topk, a device->host copy and the Python loops of Coach.calcRes
+// (main.py:168-187).  Here the score matrix never exists in memory: a wavefront owns 32 users
+// (their embeddings stay in registers as the B operand of v_mfma_f32_32x32x2_f32), item tiles of
+// 32 rows are staged through LDS as the A operand, and each lane keeps the running top-k of its
+// user over the items it sees.  A score is compared with the lane's current k-th best first;
+// only the few that pass are looked up in the user's (sorted) training row and inserted.
+#include "dg_internal.h"
+
+#include <math.h>
+
+#include <algorithm>
+#include <climits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kMaxK = 32;
+constexpr int kUsersPerBlock = 128;      // 4 wavefronts x 32 users
+constexpr int kTile = 32;                // items per tile
+constexpr int kPitch = 68;               // floats per staged item row (64 + 4: conflict-free ds_read_b128)
+constexpr float kMasked = -1e8f;         // main.py:157
+
+struct topk_args {
+  const float *usr_emb, *item_emb;
+  const int64_t *test_users;
+  const int32_t *trn_rowptr, *trn_col;
+  float *cand_score;   // [n_test][2 * n_split][k]
+  int32_t *cand_idx;
+  int32_t n_test, n_item, k, n_split, tiles_per_split;
+};
+
+// Is `item` in the ascending list col[b, e)?
+__device__ __forceinline__ bool in_row(const int32_t *__restrict__ col, int b, int e, int item) {
+  while (b < e) {
+    const int m = (b + e) >> 1, c = col[m];
+    if (c == item) return true;
+    if (c < item) b = m + 1; else e = m;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
+  extern __shared__ float smem[];
+  float *tile = smem;                                   // [2][kTile][kPitch]
+  float *lsc = smem + 2 * kTile * kPitch;               // [k][256] running top-k scores, descending
+  int *lix = reinterpret_cast<int *>(lsc + a.k * 256);  // [k][256] their item ids
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int k = a.k;
+  const int t_idx = blockIdx.x * kUsersPerBlock + wave * 32 + j;
+  const bool valid = t_idx < a.n_test;
+  const int64_t user = valid ? a.test_users[t_idx] : 0;
+
+  // B operand: features 32h .. 32h+31 of this lane's user
+  float ub[32];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (valid) v = *reinterpret_cast<const f32x4 *>(a.usr_emb + user * DG_D + 32 * h + 4 * c);
+    ub[4 * c] = v.x; ub[4 * c + 1] = v.y; ub[4 * c + 2] = v.z; ub[4 * c + 3] = v.w;
+  }
+  int row_b = 0, row_e = 0;
+  if (valid) { row_b = a.trn_rowptr[user]; row_e = a.trn_rowptr[user + 1]; }
+  for (int p = 0; p < k; ++p) { lsc[p * 256 + tid] = -INFINITY; lix[p * 256 + tid] = -1; }
+  float tau = -INFINITY;  // the lane's k-th best so far
+
+  const int tile0 = blockIdx.y * a.tiles_per_split;
+  const int n_tiles_all = (a.n_item + kTile - 1) / kTile;
+  const int tile1 = min(tile0 + a.tiles_per_split, n_tiles_all);
+  // staging: thread -> (row = tid >> 3, two float4 at columns 8 (tid & 7) and + 4)
+  auto fetch = [&](int t, f32x4 &v0, f32x4 &v1) {
+    const int item = t * kTile + (tid >> 3);
+    v0 = v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (item < a.n_item) {
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(a.item_emb + (size_t)item * DG_D + 8 * (tid & 7));
+      v0 = src[0]; v1 = src[1];
+    }
+  };
+  auto stage = [&](int buf, f32x4 v0, f32x4 v1) {
+    float *dst = tile + (buf * kTile + (tid >> 3)) * kPitch + 8 * (tid & 7);
+    *reinterpret_cast<f32x4 *>(dst) = v0;
+    *reinterpret_cast<f32x4 *>(dst + 4) = v1;
+  };
+  f32x4 p0, p1;
+  if (tile0 < tile1) { fetch(tile0, p0, p1); stage(0, p0, p1); }
+  __syncthreads();
+  for (int t = tile0; t < tile1; ++t) {
+    const int buf = (t - tile0) & 1;
+    if (t + 1 < tile1) fetch(t + 1, p0, p1);
+    // A operand: features 32h .. 32h+31 of item (t*32 + j)
+    const float *arow = tile + (buf * kTile + j) * kPitch + 32 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + 4 * c);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, ub[4 * c], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, ub[4 * c + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, ub[4 * c + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, ub[4 * c + 3], acc, 0, 0, 0);
+    }
+    // acc[r]: user j, item t*32 + 8 (r >> 2) + 4 h + (r & 3)
+    float best = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) best = fmaxf(best, acc[r]);
+    if (valid && best > tau) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = acc[r];
+        if (!(s > tau)) continue;
+        const int item = t * kTile + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (item >= a.n_item) continue;
+        if (in_row(a.trn_col, row_b, row_e, item)) s = kMasked;  // s * (1 - 1) - 1e8
+        if (!(s > tau)) continue;
+        // insert behind every entry >= s (entries of equal score keep ascending item order)
+        int p = k - 1;
+        while (p > 0 && lsc[(p - 1) * 256 + tid] < s) {
+          lsc[p * 256 + tid] = lsc[(p - 1) * 256 + tid];
+          lix[p * 256 + tid] = lix[(p - 1) * 256 + tid];
+          --p;
+        }
+        lsc[p * 256 + tid] = s;
+        lix[p * 256 + tid] = item;
+        tau = lsc[(k - 1) * 256 + tid];
+      }
+    }
+    if (t + 1 < tile1) stage(buf ^ 1, p0, p1);
+    __syncthreads();
+  }
+  if (!valid) return;
+  const size_t o = ((size_t)t_idx * 2 * a.n_split + 2 * blockIdx.y + h) * k;
+  for (int p = 0; p < k; ++p) {
+    a.cand_score[o + p] = lsc[p * 256 + tid];
+    a.cand_idx[o + p] = lix[p * 256 + tid];
+  }
+}
+
+// One wavefront per test user: the k best of its n_cand candidates, by falling score, equal
+// scores by rising item id (k rounds of a wavefront-wide arg-max).
+__global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict__ cand_score,
+                                                         const int32_t *__restrict__ cand_idx, int n_test, int n_cand,
+                                                         int k, int32_t *__restrict__ top_idx,
+                                                         float *__restrict__ top_score) {
+  const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= n_test) return;
+  constexpr int kPer = 16;  // candidates per lane (n_cand <= 1024)
+  float sc[kPer];
+  int ix[kPer];
+#pragma unroll
+  for (int c = 0; c < kPer; ++c) {
+    const int q = c * 64 + lane;
+    sc[c] = -INFINITY; ix[c] = INT_MAX;
+    if (q < n_cand) {
+      const int id = cand_idx[(size_t)u * n_cand + q];
+      if (id >= 0) { sc[c] = cand_score[(size_t)u * n_cand + q]; ix[c] = id; }
+    }
+  }
+  for (int round = 0; round < k; ++round) {
+    float bs = sc[0];
+    int bi = ix[0];
+#pragma unroll
+    for (int c = 1; c < kPer; ++c)
+      if (sc[c] > bs || (sc[c] == bs && ix[c] < bi)) { bs = sc[c]; bi = ix[c]; }
+    for (int off = 32; off > 0; off >>= 1) {
+      const float os = __shfl_xor(bs, off);
+      const int oi = __shfl_xor(bi, off);
+      if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+    }
+    if (lane == 0) {
+      top_idx[(size_t)u * k + round] = bi == INT_MAX ? -1 : bi;
+      top_score[(size_t)u * k + round] = bs;
+    }
+#pragma unroll
+    for (int c = 0; c < kPer; ++c)
+      if (ix[c] == bi) { sc[c] = -INFINITY; ix[c] = INT_MAX; }  // an item id is a candidate of one lane only
+  }
+}
+
+// Coach.calcRes for one user per thread (main.py:172-186): walks the user's test items in stored
+// order; inv_log2[p] = 1 / log2(p + 2) and max_dcg[t] = sum_{p < t} inv_log2[p] come from the host
+// in fp64, evaluated there exactly as the reference evaluates them.
+__global__ __launch_bounds__(256) void eval_metrics_kernel(const int32_t *__restrict__ top_idx, int n_test, int k,
+                                                           const int64_t *__restrict__ test_users,
+                                                           const int32_t *__restrict__ tst_rowptr,
+                                                           const int32_t *__restrict__ tst_col,
+                                                           const double *__restrict__ inv_log2,
+                                                           const double *__restrict__ max_dcg, double *__restrict__ recall,
+                                                           double *__restrict__ ndcg) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= n_test) return;
+  const int64_t user = test_users[u];
+  const int b = tst_rowptr[user], e = tst_rowptr[user + 1], tst_num = e - b;
+  int hits = 0;
+  double dcg = 0.0;
+  for (int p = b; p < e; ++p) {
+    const int val = tst_col[p];
+    for (int q = 0; q < k; ++q)
+      if (top_idx[(size_t)u * k + q] == val) {  // list.index(val): the first position
+        ++hits;
+        dcg += inv_log2[q];
+        break;
+      }
+  }
+  recall[u] = tst_num > 0 ? (double)hits / (double)tst_num : 0.0;
+  ndcg[u] = tst_num > 0 ? dcg / max_dcg[min(tst_num, k)] : 0.0;
+}
+
+// Item-range splits per user tile: enough workgroups to fill the chip twice, at most 8.
+int pick_split(int32_t n_test, int32_t n_item) {
+  const int tiles = (n_test + kUsersPerBlock - 1) / kUsersPerBlock;
+  const int n_tiles = (n_item + kTile - 1) / kTile;
+  return std::max(1, std::min(std::min((512 + tiles - 1) / tiles, 8), n_tiles));
+}
+
+}  // namespace
+
+extern "C" size_t dg_eval_topk_workspace(int32_t n_test, int32_t n_item, int32_t k) {
+  if (n_test <= 0 || n_item <= 0 || k <= 0) return 0;
+  return (size_t)n_test * 2 * pick_split(n_test, n_item) * k * (sizeof(float) + sizeof(int32_t));
+}
+
+extern "C" int dg_eval_topk(const float *usr_emb, const float *item_emb, int32_t n_user, int32_t n_item,
+                            const int64_t *test_users, int32_t n_test, const int32_t *trn_rowptr, const int32_t *trn_col,
+                            int32_t k, int32_t d, void *workspace, size_t workspace_bytes, int32_t *top_idx,
+                            float *top_score, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_eval_topk: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!usr_emb || !item_emb || !test_users || !trn_rowptr || !trn_col || !workspace || !top_idx || !top_score)
+    return dg_fail(DG_ERR_ARG, "dg_eval_topk: NULL argument");
+  if (n_user <= 0 || n_item <= 0 || n_test < 0) return dg_fail(DG_ERR_ARG, "dg_eval_topk: bad sizes");
+  if (k <= 0 || k > kMaxK) return dg_fail(DG_ERR_SIZE, "dg_eval_topk: k must be in [1,%d] (got %d)", kMaxK, k);
+  if (n_test == 0) return 0;
+  if (((uintptr_t)usr_emb | (uintptr_t)item_emb) & 15) return dg_fail(DG_ERR_ARG, "dg_eval_topk: tables must be 16-byte aligned");
+  const size_t need = dg_eval_topk_workspace(n_test, n_item, k);
+  if (workspace_bytes < need) return dg_fail(DG_ERR_SIZE, "dg_eval_topk: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+  const int tiles = (n_test + kUsersPerBlock - 1) / kUsersPerBlock;
+  const int n_split = pick_split(n_test, n_item);
+  const int n_tiles = (n_item + kTile - 1) / kTile;
+  topk_args a;
+  a.usr_emb = usr_emb; a.item_emb = item_emb; a.test_users = test_users; a.trn_rowptr = trn_rowptr; a.trn_col = trn_col;
+  a.cand_score = (float *)workspace;
+  a.cand_idx = (int32_t *)(a.cand_score + (size_t)n_test * 2 * n_split * k);
+  a.n_test = n_test; a.n_item = n_item; a.k = k; a.n_split = n_split;
+  a.tiles_per_split = (n_tiles + n_split - 1) / n_split;
+  const size_t lds = (size_t)2 * kTile * kPitch * sizeof(float) + (size_t)k * 256 * (sizeof(float) + sizeof(int));
+  static bool attr_set = false;  // up to 80 KiB of dynamic LDS has to be opted into once
+  if (!attr_set) {
+    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(score_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(2 * kTile * kPitch * sizeof(float) + kMaxK * 256 * 8)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(score_topk_kernel, dim3(tiles, n_split), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(merge_topk_kernel, dim3((n_test + 3) / 4), dim3(256), 0, (hipStream_t)stream, a.cand_score, a.cand_idx,
+                     n_test, 2 * n_split * k, k, top_idx, top_score);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dg_eval_metrics(const int32_t *top_idx, int32_t n_test, int32_t k, const int64_t *test_users,
+                               const int32_t *tst_rowptr, const int32_t *tst_col, const double *inv_log2,
+                               const double *max_dcg, double *recall, double *ndcg, void *stream) {
+  if (!top_idx || !test_users || !tst_rowptr || !tst_col || !inv_log2 || !max_dcg || !recall || !ndcg)
+    return dg_fail(DG_ERR_ARG, "dg_eval_metrics: NULL argument");
+  if (k <= 0 || n_test < 0) return dg_fail(DG_ERR_ARG, "dg_eval_metrics: bad sizes");
+  if (n_test == 0) return 0;
+  hipLaunchKernelGGL(eval_metrics_kernel, dim3((n_test + 255) / 256), dim3(256), 0, (hipStream_t)stream, top_idx, n_test, k,
+                     test_users, tst_rowptr, tst_col, inv_log2, max_dcg, recall, ndcg);
+  DG_HIP(hipGetLastError());
+  return 0;
+}

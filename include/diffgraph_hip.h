@@ -324,6 +324,33 @@ int dg_rec_head_bwd(const float *ui, const float *out_u, const float *out_i, con
                     float *d_ui, float *d_out_u, float *d_out_i, double *d_row_loss_u,
                     double *d_row_loss_i, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * All-rank evaluation.  Replaces the per-batch body of Coach.testEpoch
+ * (DiffGraph-Rec/main.py:153-160) with the dense train-mask rows of AllRankTestData
+ * (DiffGraph-Rec/DataHandler.py:268-272):
+ *     allPreds = usr_emb[u] . item_emb^T * (1 - trnMask) - trnMask * 1e8 ;  topk(allPreds, k)
+ * for the n_test users test_users[] (DEVICE int64).  The training interactions come as a CSR over
+ * users (DEVICE int32 trn_rowptr[n_user+1], trn_col[] ascending inside a row) instead of dense mask
+ * rows.  top_idx / top_score: DEVICE [n_test][k], by falling score; equal scores by rising item id
+ * (torch.topk leaves that order open); -1 where a user has fewer than k items.  k <= 32.
+ * workspace: DEVICE scratch of dg_eval_topk_workspace() bytes.
+ * ---------------------------------------------------------------------------------- */
+size_t dg_eval_topk_workspace(int32_t n_test, int32_t n_item, int32_t k);
+int dg_eval_topk(const float *usr_emb, const float *item_emb, int32_t n_user, int32_t n_item,
+                 const int64_t *test_users, int32_t n_test, const int32_t *trn_rowptr,
+                 const int32_t *trn_col, int32_t k, int32_t d, void *workspace, size_t workspace_bytes,
+                 int32_t *top_idx, float *top_score, void *stream);
+
+/* Coach.calcRes (DiffGraph-Rec/main.py:168-187) per test user: recall[u] = hits / tstNum,
+ * ndcg[u] = dcg / maxDcg in fp64, the user's test items (DEVICE int32 CSR tst_rowptr[n_user+1],
+ * tst_col[] in the order the test matrix stores them) walked in order.  inv_log2: DEVICE fp64[k] =
+ * 1/log2(p+2); max_dcg: DEVICE fp64[k+1], max_dcg[t] = sum_{p<t} inv_log2[p], both evaluated by
+ * the caller on the host the way the reference evaluates them.  The caller adds the per-user
+ * values up (the reference adds them in test-user order). */
+int dg_eval_metrics(const int32_t *top_idx, int32_t n_test, int32_t k, const int64_t *test_users,
+                    const int32_t *tst_rowptr, const int32_t *tst_col, const double *inv_log2,
+                    const double *max_dcg, double *recall, double *ndcg, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -261,3 +261,75 @@ def normalised_adj_csr(src: torch.Tensor, dst: torch.Tensor, n: int) -> torch.Te
     vals = ni[dst.long()] * no[src.long()]
     coo = torch.sparse_coo_tensor(torch.stack([dst.long(), src.long()]), vals, (n, n)).coalesce()
     return coo.to_sparse_csr()
+
+
+# --------------------------------------------------------------------------------------
+# N1: all-rank evaluation -- Coach.testEpoch main.py:147-167, Coach.calcRes main.py:168-187,
+#     AllRankTestData DataHandler.py:250-272
+# --------------------------------------------------------------------------------------
+def test_users_and_lists(n_user: int, tst_u: np.ndarray, tst_i: np.ndarray) -> Tuple[np.ndarray, List[List[int]]]:
+    """AllRankTestData.__init__ (DataHandler.py:251-263): per-user lists of test items in the order
+    the test matrix stores them, and the test users as np.array(list(set(...)))."""
+    user_pos_lists: List[List[int]] = [list() for _ in range(n_user)]
+    test_users = set()
+    for row, col in zip(tst_u.tolist(), tst_i.tolist()):
+        user_pos_lists[row].append(col)
+        test_users.add(row)
+    return np.array(list(test_users)), user_pos_lists
+
+
+def all_rank_topk(usr_emb: torch.Tensor, item_emb: torch.Tensor, users: torch.Tensor, trn_mask: torch.Tensor, topk: int = 20):
+    """main.py:157-158: scores of a batch of users against every item, training interactions pushed
+    to -1e8, then torch.topk (sorted).  trn_mask: dense {0,1} float [len(users), n_item]."""
+    all_preds = torch.mm(usr_emb[users], torch.transpose(item_emb, 1, 0)) * (1 - trn_mask) - trn_mask * 1e8
+    vals, top_locs = torch.topk(all_preds, topk)
+    return vals, top_locs
+
+
+def calc_res(top_locs: np.ndarray, tst_locs: List[List[int]], bat_ids: Sequence[int], topk: int = 20):
+    """Coach.calcRes main.py:168-187: per-user recall@k and NDCG@k (numpy float64), and their
+    sums accumulated in user order exactly as the reference does.  Returns (allRecall, allNdcg,
+    per-user recall, per-user ndcg)."""
+    all_recall = all_ndcg = 0
+    recalls, ndcgs = [], []
+    for i in range(len(bat_ids)):
+        tem_top = list(top_locs[i])
+        tem_tst = tst_locs[bat_ids[i]]
+        tst_num = len(tem_tst)
+        max_dcg = np.sum([np.reciprocal(np.log2(loc + 2)) for loc in range(min(tst_num, topk))])
+        recall = dcg = 0
+        for val in tem_tst:
+            if val in tem_top:
+                recall += 1
+                dcg += np.reciprocal(np.log2(tem_top.index(val) + 2))
+        recall = recall / tst_num
+        ndcg = dcg / max_dcg
+        all_recall += recall
+        all_ndcg += ndcg
+        recalls.append(recall)
+        ndcgs.append(ndcg)
+    return all_recall, all_ndcg, np.asarray(recalls, dtype=np.float64), np.asarray(ndcgs, dtype=np.float64)
+
+
+def test_epoch(usr_emb: torch.Tensor, item_emb: torch.Tensor, trn_u: np.ndarray, trn_i: np.ndarray, tst_u: np.ndarray,
+               tst_i: np.ndarray, topk: int = 20, tst_bat: int = 1024):
+    """Coach.testEpoch main.py:147-167 after model.predict(): batches of tst_bat test users in
+    AllRankTestData order, dense train-mask rows (DataHandler.py:268-272), top-k, calcRes; the epoch
+    metrics are the per-batch sums added up and divided by the number of test users.
+    Returns dict(Recall, NDCG, users, top_locs, recall_per_user, ndcg_per_user)."""
+    n_user, n_item = usr_emb.shape[0], item_emb.shape[0]
+    users, lists = test_users_and_lists(n_user, tst_u, tst_i)
+    mask = np.zeros((n_user, n_item), dtype=np.float32)   # (trn_mat.tocsr() != 0) * 1.0, DataHandler.py:252
+    mask[trn_u, trn_i] = 1.0
+    ep_recall = ep_ndcg = 0
+    tops, recs, nds = [], [], []
+    for b in range(0, len(users), tst_bat):
+        usr = users[b: b + tst_bat]
+        _, top_locs = all_rank_topk(usr_emb, item_emb, torch.from_numpy(usr).long(), torch.from_numpy(mask[usr]), topk)
+        r, n, rr, nn = calc_res(top_locs.numpy(), lists, usr, topk)
+        ep_recall += r
+        ep_ndcg += n
+        tops.append(top_locs.numpy()); recs.append(rr); nds.append(nn)
+    num = len(users)
+    return {"Recall": ep_recall / num, "NDCG": ep_ndcg / num, "users": users, "top_locs": np.concatenate(tops),
+            "recall_per_user": np.concatenate(recs), "ndcg_per_user": np.concatenate(nds)}

@@ -1,0 +1,115 @@
+"""GPU parity of the all-rank evaluation (Coach.testEpoch / calcRes, DiffGraph-Rec/main.py:136-187)
+against the reference's golden run and the CPU oracle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import diffgraph_amd as dg
+from diffgraph_amd import data as dgdata, evaluate as ev
+from oracle import ref_cpu as O
+from tests.helpers import load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = torch.from_numpy
+
+
+def coo(u, i, nu, ni):
+    return sp.coo_matrix((np.ones(len(u), np.float32), (u, i)), shape=(nu, ni))
+
+
+def check_top_lists(got_idx, got_val, want_idx, scores, what):
+    """Top-k lists agree with the oracle's except where the reference leaves the order open: positions whose
+    scores tie (exactly, or within fp32 rounding of the differently ordered dot products)."""
+    got_idx, want_idx = np.asarray(got_idx), np.asarray(want_idx)
+    assert got_idx.shape == want_idx.shape, what
+    for r in np.nonzero((got_idx != want_idx).any(axis=1))[0]:
+        for c in np.nonzero(got_idx[r] != want_idx[r])[0]:
+            a, b = scores[r, got_idx[r, c]], scores[r, want_idx[r, c]]
+            assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), f"{what}: user row {r} position {c}: item {got_idx[r, c]} ({a}) vs {want_idx[r, c]} ({b})"
+    np.testing.assert_allclose(got_val, np.take_along_axis(scores, want_idx.astype(np.int64), axis=1), rtol=2e-5, atol=2e-5,
+                               err_msg=what)
+
+
+def test_eval_golden_reference_test_epoch():
+    """The reference's own testEpoch run (tools/make_golden.py gen_eval): same test-user order, top-20
+    lists, per-user Recall/NDCG bit for bit and the epoch metrics."""
+    fx = load("rec_eval.npz")
+    nu, ni, k = int(fx["n_user"][0]), int(fx["n_item"][0]), int(fx["topk"][0])
+    data = ev.AllRankTestData(coo(fx["tst_u"], fx["tst_i"], nu, ni), coo(fx["trn_u"], fx["trn_i"], nu, ni))
+    np.testing.assert_array_equal(data.test_users, fx["users"])
+    res = ev.rank_metrics(T(fx["usr_emb"]).to(DEV), T(fx["item_emb"]).to(DEV), data, topk=k, tstBat=64)
+    np.testing.assert_array_equal(res["topLocs"].cpu().numpy(), fx["top_locs"])
+    np.testing.assert_array_equal(res["recall_per_user"], fx["recall_per_user"])
+    np.testing.assert_array_equal(res["ndcg_per_user"], fx["ndcg_per_user"])
+    np.testing.assert_array_equal(np.array([res["Recall"], res["NDCG"]]), fx["metrics"])
+
+
+@pytest.mark.parametrize("nu,ni,k,n_trn", [(1, 5, 3, 2), (130, 33, 20, 1500), (257, 1000, 1, 0), (500, 4099, 32, 60000),
+                                            (64, 40, 20, 2200)])
+def test_eval_ragged_sizes_against_oracle(nu, ni, k, n_trn):
+    """Ragged user / item counts, k = 1 and 32, no training data, and users whose training row leaves
+    fewer than k items (the masked ones then fill the list at -1e8, lowest item id first)."""
+    gen = torch.Generator().manual_seed(nu * 7 + ni)
+    usr, itm = torch.randn(nu, 64, generator=gen), torch.randn(ni, 64, generator=gen)
+    trn_u, trn_i = dgdata.synth_interactions(nu, ni, n_trn, 3) if n_trn else (np.zeros(0, np.int32), np.zeros(0, np.int32))
+    rng = np.random.default_rng(5)
+    tst_u, tst_i = rng.integers(0, nu, 3 * nu), rng.integers(0, ni, 3 * nu)
+    key = np.unique(tst_u.astype(np.int64) * ni + tst_i)
+    tst_u, tst_i = (key // ni).astype(np.int32), (key % ni).astype(np.int32)
+    data = ev.AllRankTestData(coo(tst_u, tst_i, nu, ni), coo(trn_u, trn_i, nu, ni))
+    users = data.test_users_dev
+    vals, top = ev.all_rank_topk(usr.to(DEV), itm.to(DEV), users, data, k)
+    mask = np.zeros((nu, ni), np.float32)
+    mask[trn_u, trn_i] = 1.0
+    m = T(mask[data.test_users])
+    scores = (torch.mm(usr[T(data.test_users).long()].double(), itm.double().t()) * (1 - m) - m * 1e8).numpy()
+    _, want = torch.topk(T(scores), min(k, ni))
+    got_idx, got_val = top.cpu().numpy(), vals.cpu().numpy()
+    if k > ni:
+        assert (got_idx[:, ni:] == -1).all()
+        got_idx, got_val = got_idx[:, :ni], got_val[:, :ni]
+    check_top_lists(got_idx, got_val, want.numpy(), scores, f"{nu}x{ni} k={k}")
+    # masked items only ever appear behind every unmasked one, in ascending id order
+    for r in range(got_idx.shape[0]):
+        masked = scores[r, got_idx[r]] <= -1e8
+        if masked.any():
+            first = int(np.argmax(masked))
+            assert masked[first:].all() and (np.diff(got_idx[r, first:]) > 0).all()
+    # metrics from the kernel's lists == the oracle's calcRes on the same lists
+    _, lists = O.test_users_and_lists(nu, tst_u, tst_i)
+    kk = min(k, ni)
+    r_all, n_all, r_u, n_u = ev.calcRes(top[:, :kk].contiguous(), data, users)
+    wr, wn, wr_u, wn_u = O.calc_res(got_idx, lists, data.test_users, topk=kk)
+    np.testing.assert_array_equal(r_u, wr_u)
+    np.testing.assert_array_equal(n_u, wn_u)
+    assert r_all == wr and n_all == wn
+
+
+def test_eval_tmall_size_sample_against_oracle():
+    """Full Tmall-shaped item table, every user a test user; 512 sampled users checked against the oracle's
+    torch.mm + topk, and size-independent properties for all: sorted scores, no training item in any list."""
+    wl = dgdata.rec_workload("tmall")
+    nu, ni, k = wl.n_user, wl.n_item, 20
+    usr = T(dgdata.xavier_uniform(nu, 64, seed=0)) * 3
+    itm = T(dgdata.xavier_uniform(ni, 64, seed=1)) * 3
+    trn_u, trn_i = wl.target
+    rng = np.random.default_rng(11)
+    tst_u = np.arange(nu, dtype=np.int32)
+    tst_i = rng.integers(0, ni, nu).astype(np.int32)
+    data = ev.AllRankTestData(coo(tst_u, tst_i, nu, ni), coo(trn_u, trn_i, nu, ni))
+    vals, top = ev.all_rank_topk(usr.to(DEV), itm.to(DEV), data.test_users_dev, data, k)
+    top_h, vals_h = top.cpu().numpy(), vals.cpu().numpy()
+    assert (np.diff(vals_h, axis=1) <= 0).all() and (top_h >= 0).all() and (top_h < ni).all()
+    trn_keys = set((trn_u.astype(np.int64) * ni + trn_i).tolist())
+    sample = rng.choice(len(data), 512, replace=False)
+    su = data.test_users[sample]
+    mask = np.zeros((512, ni), np.float32)
+    for r, u in enumerate(su):
+        mask[r, trn_i[trn_u == u]] = 1.0
+        assert not any((int(u) * ni + int(i)) in trn_keys for i in top_h[sample[r]])
+    m = T(mask)
+    scores = (torch.mm(usr[T(su).long()].double(), itm.double().t()) * (1 - m) - m * 1e8).numpy()
+    _, want = torch.topk(T(scores), k)
+    check_top_lists(top_h[sample], vals_h[sample], want.numpy(), scores, "tmall sample")

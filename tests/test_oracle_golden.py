@@ -173,3 +173,17 @@ def test_nc_forward_dblp(tag):
     assert_rows_close(emb[rows], fx[f"{tag}_allembeds_rows"], what=f"{tag} allembeds")
     scores = torch.nn.functional.linear(emb, T(fx["w_dense"]), T(fx["b_dense"]))
     assert_rows_close(scores[rows], fx[f"{tag}_scores_rows"], rtol=2e-5, what=f"{tag} scores")
+
+
+# ------------------------------------------------------------------------------ N1: all-rank evaluation
+def test_eval_oracle_matches_reference_test_epoch():
+    """oracle.test_epoch against the reference's own Coach.testEpoch + AllRankTestData
+    (tools/make_golden.py gen_eval): test-user order, top-20 lists, per-user and epoch metrics."""
+    fx = load("rec_eval.npz")
+    r = O.test_epoch(T(fx["usr_emb"]), T(fx["item_emb"]), fx["trn_u"], fx["trn_i"], fx["tst_u"], fx["tst_i"],
+                     topk=int(fx["topk"][0]), tst_bat=64)
+    np.testing.assert_array_equal(r["users"], fx["users"])
+    np.testing.assert_array_equal(r["top_locs"], fx["top_locs"])
+    np.testing.assert_array_equal(r["recall_per_user"], fx["recall_per_user"])
+    np.testing.assert_array_equal(r["ndcg_per_user"], fx["ndcg_per_user"])
+    np.testing.assert_array_equal(np.array([r["Recall"], r["NDCG"]]), fx["metrics"])

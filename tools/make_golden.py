@@ -4,7 +4,7 @@
 Run in the build container only (it needs /root/reference, which never travels):
 
     python tools/make_golden.py            # both programs, one subprocess each
-    python tools/make_golden.py rec|nc     # one of them, in this process
+    python tools/make_golden.py rec|nc|eval     # one of them, in this process
 
 How the reference is run.  Its Model.py files import `dgl` (not installed, no network) for
 exactly three things: dgl.function.copy_u / dgl.function.sum message-passing tags, a graph
@@ -354,12 +354,78 @@ def gen_nc():
     print("nc_dblp.npz:", len(fx), "arrays")
 
 
+# --------------------------------------------------------------------------------------
+# Rec all-rank evaluation (Coach.testEpoch / calcRes, AllRankTestData)
+# --------------------------------------------------------------------------------------
+def gen_eval():
+    """Runs the reference's own Coach.testEpoch (main.py:136-167) with its AllRankTestData
+    (DataHandler.py:250-272) on a small synthetic train/test split and given embeddings.  The model is
+    a stand-in whose predict() returns those embeddings; Tensor.cuda() is made the identity for the
+    run (the reference hard-codes .cuda(), main.py:154-155); the run happens in a scratch directory
+    because testEpoch pickles the embeddings into the working directory (main.py:150-152)."""
+    import tempfile
+    import scipy.sparse as sp
+    from diffgraph_amd import data as dgdata
+    install_dgl_stub()
+    sys.argv = ["make_golden"]
+    sys.path.insert(0, os.path.join(REF, "DiffGraph-Rec"))
+    import main as ref_main          # noqa: the reference's modules
+    import DataHandler as ref_dh     # noqa
+    nu, ni, k = 300, 500, 20
+    trn_u, trn_i = dgdata.synth_interactions(nu, ni, 3000, 7)
+    cand_u, cand_i = dgdata.synth_interactions(nu, ni, 900, 8)
+    trn_keys = set((trn_u.astype(np.int64) * ni + trn_i).tolist())
+    keep = np.array([(int(u) * ni + int(i)) not in trn_keys for u, i in zip(cand_u, cand_i)])
+    tst_u, tst_i = cand_u[keep], cand_i[keep]
+    # a seeded shuffle, so the per-user test lists are not sorted by item (calcRes walks them in stored order)
+    perm = np.random.default_rng(9).permutation(tst_u.size)
+    tst_u, tst_i = tst_u[perm], tst_i[perm]
+    gen = torch.Generator().manual_seed(5)
+    usr = torch.randn(nu, 64, generator=gen) * 0.3
+    itm = torch.randn(ni, 64, generator=gen) * 0.3
+    trn = sp.coo_matrix((np.ones(trn_u.size, np.float32), (trn_u, trn_i)), shape=(nu, ni))
+    tst = sp.coo_matrix((np.ones(tst_u.size, np.float32), (tst_u, tst_i)), shape=(nu, ni))
+    ds = ref_dh.AllRankTestData(tst, trn)
+    ref_main.args.tstBat, ref_main.args.topk = 64, k
+    loader = torch.utils.data.DataLoader(ds, batch_size=ref_main.args.tstBat, shuffle=False, num_workers=0)
+    coach = ref_main.Coach.__new__(ref_main.Coach)
+    coach.handler = types.SimpleNamespace(test_dataloader=loader, userNum=nu, itemNum=ni)
+    coach.model = types.SimpleNamespace(eval=lambda: None, predict=lambda: (usr, itm))
+    captured = []
+    real_calc = coach.calcRes
+
+    def calc(topLocs, tstLocs, batIds):
+        captured.append((np.array(topLocs), np64(batIds)))
+        return real_calc(topLocs, tstLocs, batIds)
+
+    coach.calcRes = calc
+    cwd, real_cuda = os.getcwd(), torch.Tensor.cuda
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        torch.Tensor.cuda = lambda self, *a, **kw: self
+        try:
+            ret = coach.testEpoch()
+        finally:
+            torch.Tensor.cuda = real_cuda
+            os.chdir(cwd)
+    top = np.concatenate([c[0] for c in captured])
+    users = np.concatenate([c[1] for c in captured])
+    per = [real_calc(top[j: j + 1], ds.user_pos_lists, users[j: j + 1]) for j in range(len(users))]
+    fx = {"n_user": np.array([nu]), "n_item": np.array([ni]), "topk": np.array([k]), "usr_emb": np64(usr), "item_emb": np64(itm),
+          "trn_u": trn_u, "trn_i": trn_i, "tst_u": tst_u, "tst_i": tst_i, "users": users, "top_locs": top,
+          "recall_per_user": np.array([p[0] for p in per], dtype=np.float64),
+          "ndcg_per_user": np.array([p[1] for p in per], dtype=np.float64),
+          "metrics": np.array([ret["Recall"], ret["NDCG"]], dtype=np.float64)}
+    np.savez_compressed(os.path.join(OUT, "rec_eval.npz"), **fx)
+    print("rec_eval.npz:", len(fx), "arrays; test users", len(users), "Recall/NDCG", ret)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "nc"]
+    which = sys.argv[1:] or ["rec", "nc", "eval"]
     if len(which) == 1:
-        {"rec": gen_rec, "nc": gen_nc}[which[0]]()
+        {"rec": gen_rec, "nc": gen_nc, "eval": gen_eval}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
             subprocess.run([sys.executable, os.path.abspath(__file__), w], check=True)
