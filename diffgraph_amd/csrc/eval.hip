@@ -7,9 +7,11 @@
 // (1 - mask) - mask * 1e8, t.topk, a device->host copy and the Python loops of Coach.calcRes
 // (main.py:168-187).  Here the score matrix never exists in memory: a wavefront owns 32 users
 // (their embeddings stay in registers as the B operand of v_mfma_f32_32x32x2_f32), item tiles of
-// 32 rows are staged through LDS as the A operand, and each lane keeps the running top-k of its
-// user over the items it sees.  A score is compared with the lane's current k-th best first;
-// only the few that pass are looked up in the user's (sorted) training row and inserted.
+// 32 rows are staged through LDS as the A operand, and each lane keeps the k best scores of its
+// user over the items it sees (a sorted list in registers, updated by a compare-and-shift network).
+// The user's sorted training row is walked in step with the item tiles, so masking costs a register
+// compare per tile; a score is compared with the worst entry of the lane's list, and of the list
+// the other half-wavefront keeps for the same user, before anything else happens to it.
 #include "dg_internal.h"
 
 #include <math.h>
@@ -37,21 +39,21 @@ struct topk_args {
   int32_t n_test, n_item, k, n_split, tiles_per_split;
 };
 
-// Is `item` in the ascending list col[b, e)?
-__device__ __forceinline__ bool in_row(const int32_t *__restrict__ col, int b, int e, int item) {
+// First position in the ascending list col[b, e) whose entry is >= item.
+__device__ __forceinline__ int lower_bound(const int32_t *__restrict__ col, int b, int e, int item) {
   while (b < e) {
-    const int m = (b + e) >> 1, c = col[m];
-    if (c == item) return true;
-    if (c < item) b = m + 1; else e = m;
+    const int m = (b + e) >> 1;
+    if (col[m] < item) b = m + 1; else e = m;
   }
-  return false;
+  return b;
 }
 
+// KPAD: list slots per lane (k rounded up to a multiple of 8).  The list lives in registers, sorted by
+// falling score; slots [0, KPAD - k) hold +inf and never move, so the lane's worst entry is always
+// the last slot.  A new score enters through a compare-and-shift over all slots (no indexed access).
+template <int KPAD>
 __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
-  extern __shared__ float smem[];
-  float *tile = smem;                                   // [2][kTile][kPitch]
-  float *lsc = smem + 2 * kTile * kPitch;               // [k][256] running top-k scores, descending
-  int *lix = reinterpret_cast<int *>(lsc + a.k * 256);  // [k][256] their item ids
+  __shared__ float tile[2 * kTile * kPitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
   const int k = a.k;
   const int t_idx = blockIdx.x * kUsersPerBlock + wave * 32 + j;
@@ -66,14 +68,21 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
     if (valid) v = *reinterpret_cast<const f32x4 *>(a.usr_emb + user * DG_D + 32 * h + 4 * c);
     ub[4 * c] = v.x; ub[4 * c + 1] = v.y; ub[4 * c + 2] = v.z; ub[4 * c + 3] = v.w;
   }
-  int row_b = 0, row_e = 0;
-  if (valid) { row_b = a.trn_rowptr[user]; row_e = a.trn_rowptr[user + 1]; }
-  for (int p = 0; p < k; ++p) { lsc[p * 256 + tid] = -INFINITY; lix[p * 256 + tid] = -1; }
-  float tau = -INFINITY;  // the lane's k-th best so far
+  float ls[KPAD];
+  int li[KPAD];
+#pragma unroll
+  for (int p = 0; p < KPAD; ++p) { ls[p] = p < KPAD - k ? INFINITY : -INFINITY; li[p] = -1; }
 
   const int tile0 = blockIdx.y * a.tiles_per_split;
   const int n_tiles_all = (a.n_item + kTile - 1) / kTile;
   const int tile1 = min(tile0 + a.tiles_per_split, n_tiles_all);
+  // the user's training items, walked in step with the item tiles (both ascend)
+  int cur = 0, row_e = 0, nxt = INT_MAX;
+  if (valid) {
+    row_e = a.trn_rowptr[user + 1];
+    cur = lower_bound(a.trn_col, a.trn_rowptr[user], row_e, tile0 * kTile);
+    if (cur < row_e) nxt = a.trn_col[cur];
+  }
   // staging: thread -> (row = tid >> 3, two float4 at columns 8 (tid & 7) and + 4)
   auto fetch = [&](int t, f32x4 &v0, f32x4 &v1) {
     const int item = t * kTile + (tid >> 3);
@@ -108,28 +117,44 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, ub[4 * c + 3], acc, 0, 0, 0);
     }
     // acc[r]: user j, item t*32 + 8 (r >> 2) + 4 h + (r & 3)
+    const int item0 = t * kTile;
+    while (nxt < item0 + kTile) {  // training items inside this tile: s * (1 - 1) - 1e8 (rare)
+      const int local = nxt - item0;
+      if (((local >> 2) & 1) == h) {
+        const int rr = ((local >> 3) << 2) | (local & 3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = r == rr ? kMasked : acc[r];
+      }
+      ++cur;
+      nxt = cur < row_e ? a.trn_col[cur] : INT_MAX;
+    }
+    if (item0 + kTile > a.n_item) {  // the last tile's rows past the table
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (item0 + 8 * (r >> 2) + 4 * h + (r & 3) >= a.n_item) acc[r] = -INFINITY;
+    }
+    // the other half-wavefront holds the same user's list over the other items of each tile: nothing
+    // below ITS worst entry can be among the user's k best either
+    const float tau_other = __shfl_xor(ls[KPAD - 1], 32);
     float best = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) best = fmaxf(best, acc[r]);
-    if (valid && best > tau) {
+    if (valid && best > ls[KPAD - 1] && best >= tau_other) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float s = acc[r];
-        if (!(s > tau)) continue;
-        const int item = t * kTile + 8 * (r >> 2) + 4 * h + (r & 3);
-        if (item >= a.n_item) continue;
-        if (in_row(a.trn_col, row_b, row_e, item)) s = kMasked;  // s * (1 - 1) - 1e8
-        if (!(s > tau)) continue;
-        // insert behind every entry >= s (entries of equal score keep ascending item order)
-        int p = k - 1;
-        while (p > 0 && lsc[(p - 1) * 256 + tid] < s) {
-          lsc[p * 256 + tid] = lsc[(p - 1) * 256 + tid];
-          lix[p * 256 + tid] = lix[(p - 1) * 256 + tid];
-          --p;
+        const float s = acc[r];
+        if (!(s > ls[KPAD - 1] && s >= tau_other)) continue;  // equal scores: the earlier (lower) item id stays
+        const int id = item0 + 8 * (r >> 2) + 4 * h + (r & 3);
+        // slot p takes its upper neighbour when s beats that one too, s when it beats only slot p's entry
+        bool above = s > ls[KPAD - 2];
+#pragma unroll
+        for (int p = KPAD - 1; p >= 1; --p) {
+          const bool here = p == KPAD - 1 ? true : s > ls[p];
+          ls[p] = above ? ls[p - 1] : (here ? s : ls[p]);
+          li[p] = above ? li[p - 1] : (here ? id : li[p]);
+          if (p >= 2) above = s > ls[p - 2];
         }
-        lsc[p * 256 + tid] = s;
-        lix[p * 256 + tid] = item;
-        tau = lsc[(k - 1) * 256 + tid];
+        if (s > ls[0]) { ls[0] = s; li[0] = id; }
       }
     }
     if (t + 1 < tile1) stage(buf ^ 1, p0, p1);
@@ -137,10 +162,9 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
   }
   if (!valid) return;
   const size_t o = ((size_t)t_idx * 2 * a.n_split + 2 * blockIdx.y + h) * k;
-  for (int p = 0; p < k; ++p) {
-    a.cand_score[o + p] = lsc[p * 256 + tid];
-    a.cand_idx[o + p] = lix[p * 256 + tid];
-  }
+#pragma unroll
+  for (int p = 0; p < KPAD; ++p)
+    if (p >= KPAD - k) { a.cand_score[o + p - (KPAD - k)] = ls[p]; a.cand_idx[o + p - (KPAD - k)] = li[p]; }
 }
 
 // One wavefront per test user: the k best of its n_cand candidates, by falling score, equal
@@ -213,11 +237,12 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(const int32_t *__rest
   ndcg[u] = tst_num > 0 ? dcg / max_dcg[min(tst_num, k)] : 0.0;
 }
 
-// Item-range splits per user tile: enough workgroups to fill the chip twice, at most 8.
+// Item-range splits per user tile: about 1.5 workgroups per CU, at most 8 (every split keeps its own
+// candidate lists, and a list over fewer items is replaced more often per item).
 int pick_split(int32_t n_test, int32_t n_item) {
   const int tiles = (n_test + kUsersPerBlock - 1) / kUsersPerBlock;
   const int n_tiles = (n_item + kTile - 1) / kTile;
-  return std::max(1, std::min(std::min((512 + tiles - 1) / tiles, 8), n_tiles));
+  return std::max(1, std::min(std::min((384 + tiles - 1) / tiles, 8), n_tiles));
 }
 
 }  // namespace
@@ -249,14 +274,10 @@ extern "C" int dg_eval_topk(const float *usr_emb, const float *item_emb, int32_t
   a.cand_idx = (int32_t *)(a.cand_score + (size_t)n_test * 2 * n_split * k);
   a.n_test = n_test; a.n_item = n_item; a.k = k; a.n_split = n_split;
   a.tiles_per_split = (n_tiles + n_split - 1) / n_split;
-  const size_t lds = (size_t)2 * kTile * kPitch * sizeof(float) + (size_t)k * 256 * (sizeof(float) + sizeof(int));
-  static bool attr_set = false;  // up to 80 KiB of dynamic LDS has to be opted into once
-  if (!attr_set) {
-    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(score_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(2 * kTile * kPitch * sizeof(float) + kMaxK * 256 * 8)));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(score_topk_kernel, dim3(tiles, n_split), dim3(256), lds, (hipStream_t)stream, a);
+  const int kpad = (k + 7) / 8 * 8;
+  void (*kern)(const topk_args) = kpad == 8 ? score_topk_kernel<8> : kpad == 16 ? score_topk_kernel<16>
+                                  : kpad == 24 ? score_topk_kernel<24> : score_topk_kernel<32>;
+  hipLaunchKernelGGL(kern, dim3(tiles, n_split), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(merge_topk_kernel, dim3((n_test + 3) / 4), dim3(256), 0, (hipStream_t)stream, a.cand_score, a.cand_idx,
                      n_test, 2 * n_split * k, k, top_idx, top_score);
   DG_HIP(hipGetLastError());
