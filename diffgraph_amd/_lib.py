@@ -53,6 +53,14 @@ class PSampleTask(C.Structure):
                 ("n", C.c_int64)]
 
 
+class LossTask(C.Structure):
+    _fields_ = [("dn", C.POINTER(Denoiser)), ("time_bias", C.c_void_p), ("target", C.c_void_p), ("x_start", C.c_void_p),
+                ("noise", C.c_void_p), ("ts", C.c_void_p), ("n", C.c_int64), ("out", C.c_void_p), ("row_loss", C.c_void_p),
+                ("g_row_loss", C.c_void_p), ("g_out", C.c_void_p), ("d_target_add", C.c_void_p), ("d_x_start", C.c_void_p),
+                ("d_target", C.c_void_p), ("dout_tot", C.c_void_p), ("hid", C.c_void_p), ("dpre", C.c_void_p),
+                ("xn", C.c_void_p)]
+
+
 # name -> (restype, argtypes); one entry per symbol declared in include/diffgraph_hip.h
 SIGNATURES = {
     "dg_version": (C.c_int, []),
@@ -88,6 +96,10 @@ SIGNATURES = {
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dg_diffusion_loss_bwd": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_int32] + [C.c_void_p] * 9 +
                               [C.c_int64, C.c_int32] + [C.c_void_p] * 7),
+    "dg_diffusion_loss_fwd_batched": (C.c_int, [C.POINTER(LossTask), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int32, C.c_void_p]),
+    "dg_diffusion_loss_bwd_batched": (C.c_int, [C.POINTER(LossTask), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int32, C.c_void_p]),
     "dg_denoiser_wgrad_workspace": (C.c_size_t, [C.c_int32]),
     "dg_denoiser_wgrad": (C.c_int, [C.POINTER(Denoiser), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_size_t] + [C.c_void_p] * 7),

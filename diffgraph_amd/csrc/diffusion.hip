@@ -48,6 +48,7 @@ struct dn_task {
   const double *g_row;                // dL/d row_loss [n]
   const float *g_out;                 // dL/d out [n][64] or NULL
   float *d_x_start, *d_target;        // [n][64]
+  const float *d_target_add;          // [n][64] added into d_target (a gradient that reached the target elsewhere), or NULL
   float *dout_tot, *hid, *dpre, *xn;  // [n][64] each: operands of the weight-gradient GEMMs
   int64_t n;
   int32_t n_steps, norm, blk_begin;
@@ -273,6 +274,12 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
     if (valid) coef = (float)(T.g_row[row] * T.loss_w[t] * (2.0 / DG_D));
     f32x16 dl[2] = {coef * (out[0] - tg[0]), coef * (out[1] - tg[1])};
     f32x16 ng[2] = {-dl[0], -dl[1]};
+    if (T.d_target_add != nullptr) {
+      f32x16 base[2];
+      load_tile(T.d_target_add + ro, h, valid, base);
+      ng[0] += base[0];
+      ng[1] += base[1];
+    }
     store_tile(T.d_target + ro, h, valid, ng);
     out[0] = dl[0];
     out[1] = dl[1];
@@ -503,4 +510,68 @@ extern "C" int dg_diffusion_loss_bwd(const dg_denoiser *dn, const float *time_bi
   hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, batch);
   DG_HIP(hipGetLastError());
   return 0;
+}
+
+// -- both denoisers of the recommendation model (users, items) in one launch each way ----------------
+namespace {
+int fill_loss_task(const char *who, const dg_loss_task &t, int32_t n_steps, int32_t d, const float *sqrt_ac,
+                   const float *sqrt_1mac, const double *loss_w, bool bwd, dn_task &k) {
+  int rc = check_denoiser(who, t.dn, t.time_bias, n_steps, d);
+  if (rc) return rc;
+  if (t.n < 0) return dg_fail(DG_ERR_ARG, "%s: negative row count", who);
+  if (t.n == 0) return 0;
+  if (!t.target || !t.x_start || !t.ts || (sqrt_ac && !t.noise)) return dg_fail(DG_ERR_ARG, "%s: NULL table", who);
+  k = dn_task{};
+  k.w_in = t.dn->w_in; k.w_out = t.dn->w_out; k.b_out = t.dn->b_out; k.time_bias = t.time_bias;
+  k.x = t.x_start; k.noise = t.noise; k.target = t.target; k.t = t.ts; k.sqrt_ac = sqrt_ac; k.sqrt_1mac = sqrt_1mac;
+  k.loss_w = loss_w; k.n = t.n; k.n_steps = n_steps; k.norm = t.dn->norm;
+  if (!bwd) {
+    if (!t.out || !t.row_loss) return dg_fail(DG_ERR_ARG, "%s: NULL output", who);
+    k.out = t.out; k.row_loss = t.row_loss;
+  } else {
+    if (!t.g_row_loss || !t.d_x_start || !t.d_target || !t.dout_tot || !t.hid || !t.dpre || !t.xn)
+      return dg_fail(DG_ERR_ARG, "%s: NULL backward argument", who);
+    k.g_row = t.g_row_loss; k.g_out = t.g_out; k.d_target_add = t.d_target_add; k.d_x_start = t.d_x_start;
+    k.d_target = t.d_target; k.dout_tot = t.dout_tot; k.hid = t.hid; k.dpre = t.dpre; k.xn = t.xn;
+  }
+  return 0;
+}
+
+int loss_batched(const char *who, const dg_loss_task *tasks, int32_t n_tasks, int32_t n_steps, const float *sqrt_ac,
+                 const float *sqrt_1mac, const double *loss_w, int32_t d, bool bwd, hipStream_t stream) {
+  if (!tasks || n_tasks <= 0 || n_tasks > kDnMaxTasks) return dg_fail(DG_ERR_ARG, "%s: n_tasks must be in [1,%d]", who, kDnMaxTasks);
+  if (!loss_w || (sqrt_ac != nullptr) != (sqrt_1mac != nullptr)) return dg_fail(DG_ERR_ARG, "%s: bad schedule tables", who);
+  dn_batch batch;
+  batch.n_tasks = 0;
+  int64_t blocks = 0;
+  for (int i = 0; i < n_tasks; ++i) {
+    dn_task k;
+    int rc = fill_loss_task(who, tasks[i], n_steps, d, sqrt_ac, sqrt_1mac, loss_w, bwd, k);
+    if (rc) return rc;
+    if (tasks[i].n == 0) continue;
+    k.blk_begin = (int32_t)blocks;
+    blocks += (tasks[i].n + kRowsPerBlock - 1) / kRowsPerBlock;
+    batch.t[batch.n_tasks++] = k;
+  }
+  if (batch.n_tasks == 0) return 0;
+  for (int i = batch.n_tasks; i < kDnMaxTasks; ++i) batch.t[i] = batch.t[0];
+  if (bwd) hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, batch);
+  else hipLaunchKernelGGL(denoise_kernel<MODE_LOSS>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, batch);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int dg_diffusion_loss_fwd_batched(const dg_loss_task *tasks, int32_t n_tasks, int32_t n_steps,
+                                             const float *sqrt_ac, const float *sqrt_1mac, const double *loss_w, int32_t d,
+                                             void *stream) {
+  return loss_batched("dg_diffusion_loss_fwd_batched", tasks, n_tasks, n_steps, sqrt_ac, sqrt_1mac, loss_w, d, false,
+                      (hipStream_t)stream);
+}
+
+extern "C" int dg_diffusion_loss_bwd_batched(const dg_loss_task *tasks, int32_t n_tasks, int32_t n_steps,
+                                             const float *sqrt_ac, const float *sqrt_1mac, const double *loss_w, int32_t d,
+                                             void *stream) {
+  return loss_batched("dg_diffusion_loss_bwd_batched", tasks, n_tasks, n_steps, sqrt_ac, sqrt_1mac, loss_w, d, true,
+                      (hipStream_t)stream);
 }

@@ -160,16 +160,23 @@ __global__ __launch_bounds__(256) void head_scatter_kernel(const int64_t *ancs, 
   if (scan) {
     const int *list = user ? idx : idx + n_batch;
     int left = c - 1;
-    for (int j0 = (e + 1) & ~15; left > 0 && j0 < m; j0 += 16) {
-      const int j = j0 + l;
-      const bool hit = j > e && j < m && list[j] == row;
-      unsigned mask = (unsigned)(__ballot(hit) >> (16 * q)) & 0xffffu;
-      while (mask) {
-        const int jj = j0 + __builtin_ctz(mask);
-        mask &= mask - 1;
-        acc += G[(size_t)jj * 16 + l];
-        n_loss += (user || jj < n_batch) ? 1 : 0;
-        --left;
+    for (int j0 = (e + 1) & ~15; left > 0 && j0 < m; j0 += 128) {  // eight 16-entry chunks per step
+      bool hit[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + 16 * u + l;
+        hit[u] = j > e && j < m && list[j] == row;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        unsigned mask = (unsigned)(__ballot(hit[u]) >> (16 * q)) & 0xffffu;
+        while (mask) {
+          const int jj = j0 + 16 * u + __builtin_ctz(mask);
+          mask &= mask - 1;
+          acc += G[(size_t)jj * 16 + l];
+          n_loss += (user || jj < n_batch) ? 1 : 0;
+          --left;
+        }
       }
     }
   }

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const fin_args a) {
   const int slice = threadIdx.x >> 5, f = blockIdx.x * 32 + (threadIdx.x & 31);
   float s = 0.f;
   if (f < kPartFloats)
+#pragma unroll 8
     for (int g = slice * (kGroups / 8); g < (slice + 1) * (kGroups / 8); ++g) s += a.partials[(size_t)g * kPartFloats + f];
   part[slice][threadIdx.x & 31] = s;
   __syncthreads();

@@ -96,6 +96,49 @@ class _RecHeadFn(torch.autograd.Function):
         return d_ui, d_out_u, d_out_i, d_rl_u, d_rl_i, None, None, None, None, None, None
 
 
+class _RecLossFn(torch.autograd.Function):
+    """Everything of cal_loss after the propagation (Model.py:96-111) as ONE differentiable op over the two
+    [n_user + n_item, 64] tables: both training_losses2 calls (one launch, user rows through usr_denoiser,
+    item rows through item_denoiser) and the loss head.  The backward runs the head, one launch for both
+    diffusion losses -- the head's gradient of the target embeddings is added inside it -- and the weight
+    gradients of the two denoisers.  Returns fp64[4] = (loss, bprLoss, regLoss, diff_loss)."""
+
+    @staticmethod
+    def forward(ctx, ui, het, noise, ts, ancs, poss, negs, model, validate, *weights):
+        gd, args, nu = model.diffusion_process, model.args, model.n_user
+        dev = ui.device
+        ui, het = ui.contiguous(), het.contiguous()
+        spans = []
+        for dn, begin, n in ((model.usr_denoiser, 0, nu), (model.item_denoiser, nu, model.n_item)):
+            p = dn.params(bool(dn.norm))
+            p.time_bias(gd.steps, refresh=True)
+            spans.append(ops.LossSpan(p, begin, n))
+        sa = gd._dev("sqrt_alphas_cumprod", dev) if gd.noise_scale != 0 else None
+        sb = gd._dev("sqrt_one_minus_alphas_cumprod", dev) if gd.noise_scale != 0 else None
+        lw = gd._dev("loss_weight", dev, torch.float64)
+        row_loss, out = ops.diffusion_loss_fwd_spans(spans, ui, het, noise, ts, sa, sb, lw, validate=validate)
+        results, ent_f = ops.rec_head_fwd(ui, out[:nu], out[nu:], row_loss[:nu], row_loss[nu:], ancs, poss, negs, nu,
+                                          float(args.batch), float(args.reg))
+        ctx.save_for_backward(ui, het, noise if noise is not None else het, ts, out, ancs, poss, negs, ent_f)
+        ctx.aux = (model, spans, sa, sb, lw)
+        return results
+
+    @staticmethod
+    def backward(ctx, g):
+        ui, het, noise, ts, out, ancs, poss, negs, ent_f = ctx.saved_tensors
+        model, spans, sa, sb, lw = ctx.aux
+        gd, args, nu = model.diffusion_process, model.args, model.n_user
+        d_ui_head, d_out, d_rl = ops.rec_head_bwd(ui, out[:nu], out[nu:], ancs, poss, negs, nu, float(args.batch),
+                                                  float(args.reg), ent_f, g.contiguous(), full=True)
+        d_het, d_ui, dout, hid, dpre, xn = ops.diffusion_loss_bwd_spans(spans, ui, het, noise, ts, sa, sb, lw, d_rl, d_out,
+                                                                        d_target_add=d_ui_head)
+        grads = []
+        for sp in spans:
+            r = slice(sp.begin, sp.begin + sp.n)
+            grads += list(ops.denoiser_wgrad(sp.dn, gd.steps, ts[r], dout[r], hid[r], dpre[r], xn[r]))
+        return (d_ui, d_het, None, None, None, None, None, None, None) + tuple(grads)
+
+
 class HGDM(nn.Module):
     def __init__(self, data_handler, args=None, device="cuda"):
         super().__init__()
@@ -176,17 +219,27 @@ class HGDM(nn.Module):
         return ui[:nu], ui[nu:], het[:nu], het[nu:]
 
     def cal_loss(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None):  # Model.py:94-111
-        args = self.args
-        ui, het = self.propagate(self.embedding_table)
-        nu = self.n_user
-        usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = ui[:nu], ui[nu:], het[:nu], het[nu:]
+        ui, het = self.propagate(self.embedding_table)   # [users | items] tables: target-graph sums, behaviour sums
         dp = self.diffusion_process
-        # everything after the two denoiser passes is one fused op over the full tables (see _RecHeadFn)
-        row_loss_u, diff_usrEmbeds = dp.training_losses_rows(self.usr_denoiser, usrEmbeds, h_usrEmbeds, ts_u, noise_u)
-        row_loss_i, diff_itemEmbeds = dp.training_losses_rows(self.item_denoiser, itmEmbeds, h_itemEmbeds, ts_i, noise_i)
+        n = ui.shape[0]
+        validate = ts_u is not None or ts_i is not None  # caller-supplied timesteps are range-checked (one host sync)
+        if ts_u is None and ts_i is None:
+            ts = torch.randint(0, dp.steps, (n,), device=ui.device).long()           # Model.py:352, both calls at once
+        else:
+            ts = torch.cat([ts_u, ts_i]).long().contiguous()
+        noise = None
+        if dp.noise_scale != 0:
+            noise = torch.randn_like(ui) if noise_u is None and noise_i is None else torch.cat([noise_u, noise_i]).contiguous()
+        for dn in (self.usr_denoiser, self.item_denoiser):
+            if dn.training and dn.drop.p > 0:
+                raise ops.DiffGraphHipError("training-mode dropout inside training_losses2 is not fused; call model.eval() "
+                                            "(the reference runs with dropout off after its first epoch)")
         ancs, poss, negs = (v.long().contiguous() for v in (ancs, poss, negs))
-        res = _RecHeadFn.apply(ui, diff_usrEmbeds, diff_itemEmbeds, row_loss_u, row_loss_i, ancs, poss, negs, self.n_user,
-                               float(args.batch), float(args.reg))
+        weights = []
+        for dn in (self.usr_denoiser, self.item_denoiser):
+            weights += [dn.emb_layer.weight, dn.emb_layer.bias, dn.in_layers[0].weight, dn.in_layers[0].bias,
+                        dn.out_layers[0].weight, dn.out_layers[0].bias]
+        res = _RecLossFn.apply(ui, het, noise, ts, ancs, poss, negs, self, validate, *weights)
         return res[0], res[1], res[2], res[3]
 
     def predict(self):  # Model.py:112-118

@@ -338,6 +338,78 @@ def diffusion_loss_bwd(dn: DenoiserParams, target, x_start, noise, ts, sqrt_ac, 
     return tuple(outs)
 
 
+@dataclass
+class LossSpan:
+    """Rows [begin, begin + n) of the shared tables go through denoiser `dn` (diffusion_loss_*_spans)."""
+    dn: DenoiserParams
+    begin: int
+    n: int
+
+
+def _span_tasks(spans: Sequence[LossSpan], n_steps: int, tables: dict):
+    arr = (_lib.LossTask * len(spans))()
+    for k, sp in enumerate(spans):
+        t = _lib.LossTask()
+        t.dn = C.pointer(sp.dn.c)
+        t.time_bias = sp.dn.time_bias(n_steps).data_ptr()
+        t.n = sp.n
+        for name, (tensor, row_bytes) in tables.items():
+            setattr(t, name, None if tensor is None else tensor.data_ptr() + sp.begin * row_bytes)
+        arr[k] = t
+    return arr
+
+
+def diffusion_loss_fwd_spans(spans: Sequence[LossSpan], target, x_start, noise, ts, sqrt_ac, sqrt_1mac, loss_w,
+                             validate: bool = True):
+    """diffusion_loss_fwd over one set of [N,64] tables whose row spans use different denoisers (the user rows
+    and the item rows of the recommendation model), in ONE launch.  Returns (row_loss fp64 [N], out [N,64])."""
+    n = x_start.shape[0]
+    _table(x_start, "x_start")
+    _table(target, "targetEmbeds", n)
+    n_steps = loss_w.numel()
+    _vec(loss_w, "loss weights", torch.float64)
+    _check_t(ts, n, n_steps, validate)
+    if sqrt_ac is not None:
+        _table(noise, "noise", n)
+        _vec(sqrt_ac, "sqrt_alphas_cumprod", torch.float32, n_steps)
+        _vec(sqrt_1mac, "sqrt_one_minus_alphas_cumprod", torch.float32, n_steps)
+    if sum(sp.n for sp in spans) != n or any(sp.begin < 0 or sp.begin + sp.n > n for sp in spans):
+        raise DiffGraphHipError("row spans must tile the tables")
+    out = torch.empty_like(x_start)
+    row_loss = torch.empty(n, dtype=torch.float64, device=x_start.device)
+    rb = DG_D * 4
+    arr = _span_tasks(spans, n_steps, {"target": (target, rb), "x_start": (x_start, rb),
+                                       "noise": (noise if sqrt_ac is not None else None, rb), "ts": (ts, 8), "out": (out, rb),
+                                       "row_loss": (row_loss, 8)})
+    rc = _lib.load().dg_diffusion_loss_fwd_batched(arr, len(spans), n_steps, _ptr(sqrt_ac), _ptr(sqrt_1mac), loss_w.data_ptr(),
+                                                   DG_D, _lib.stream_ptr(x_start.device))
+    _lib.check(rc, "dg_diffusion_loss_fwd_batched")
+    return row_loss, out
+
+
+def diffusion_loss_bwd_spans(spans: Sequence[LossSpan], target, x_start, noise, ts, sqrt_ac, sqrt_1mac, loss_w, g_row_loss,
+                             g_out, d_target_add=None):
+    """Backward of diffusion_loss_fwd_spans in ONE launch.  d_target_add ([N,64] or None) is added into d_target.
+    Returns (d_x_start, d_target, dout_tot, hid, dpre, xn), all [N,64]."""
+    n = x_start.shape[0]
+    n_steps = loss_w.numel()
+    _vec(g_row_loss, "grad of row_loss", torch.float64, n)
+    for nm, t in (("grad of out", g_out), ("d_target_add", d_target_add)):
+        if t is not None:
+            _table(t, nm, n)
+    outs = [torch.empty_like(x_start) for _ in range(6)]
+    rb = DG_D * 4
+    names = ("d_x_start", "d_target", "dout_tot", "hid", "dpre", "xn")
+    tables = {"target": (target, rb), "x_start": (x_start, rb), "noise": (noise if sqrt_ac is not None else None, rb),
+              "ts": (ts, 8), "g_row_loss": (g_row_loss, 8), "g_out": (g_out, rb), "d_target_add": (d_target_add, rb)}
+    tables.update({nm: (o, rb) for nm, o in zip(names, outs)})
+    arr = _span_tasks(spans, n_steps, tables)
+    rc = _lib.load().dg_diffusion_loss_bwd_batched(arr, len(spans), n_steps, _ptr(sqrt_ac), _ptr(sqrt_1mac), loss_w.data_ptr(),
+                                                   DG_D, _lib.stream_ptr(x_start.device))
+    _lib.check(rc, "dg_diffusion_loss_bwd_batched")
+    return tuple(outs)
+
+
 def denoiser_wgrad(dn: DenoiserParams, n_steps: int, ts, dout, hid, dpre, xn):
     """Weight gradients of the denoiser from the tables of diffusion_loss_bwd.
     Returns (d_w_emb [8,8], d_b_emb [8], d_w_in [64,72], d_b_in [64], d_w_out [64,64], d_b_out [64])."""
@@ -369,7 +441,8 @@ def _index_vec(v: torch.Tensor, name: str, n: int) -> None:
 
 
 def rec_head_fwd(ui, out_u, out_i, row_loss_u, row_loss_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float):
-    """Loss head of HGDM.cal_loss (Model.py:101-111).  Returns (results fp64[4] = loss, bpr, reg, diff; entries_f)."""
+    """Loss head of HGDM.cal_loss (Model.py:101-111).  Returns (results fp64[4] = loss, bpr, reg, diff; entries_f).
+    out_u / out_i and row_loss_u / row_loss_i may be the two row spans of one table."""
     n_item = ui.shape[0] - n_user
     B = ancs.numel()
     _table(ui, "ui")
@@ -391,9 +464,10 @@ def rec_head_fwd(ui, out_u, out_i, row_loss_u, row_loss_i, ancs, poss, negs, n_u
     return results, ent_f
 
 
-def rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float, ent_f, g):
+def rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float, ent_f, g, full: bool = False):
     """Backward of rec_head_fwd; g: fp64[4] upstream gradients.  Returns dense (d_ui, d_out_u, d_out_i,
-    d_row_loss_u, d_row_loss_i), zero outside the batch rows."""
+    d_row_loss_u, d_row_loss_i), zero outside the batch rows; with full=True (d_ui, d_out [N,64], d_row_loss [N])
+    -- the user and item parts as one table each."""
     n, n_item = ui.shape[0], ui.shape[0] - n_user
     B = ancs.numel()
     _vec(g, "upstream gradients", torch.float64, 4)
@@ -413,4 +487,6 @@ def rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user: int, batch_div: flo
                                      g.data_ptr(), scratch.data_ptr(), tags.data_ptr(), d_ui.data_ptr(), d_out_u.data_ptr(),
                                      d_out_i.data_ptr(), d_rl_u.data_ptr(), d_rl_i.data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "dg_rec_head_bwd")
+    if full:
+        return d_ui, d_out, d_rl
     return d_ui, d_out_u, d_out_i, d_rl_u, d_rl_i

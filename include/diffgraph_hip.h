@@ -272,6 +272,32 @@ int dg_diffusion_loss_bwd(const dg_denoiser *dn, const float *time_bias, int32_t
                           int64_t n, int32_t d, float *d_x_start, float *d_target, float *dout_tot,
                           float *hid, float *dpre, float *xn, void *stream);
 
+/* dg_diffusion_loss_fwd / _bwd for several (denoiser, table) pairs in ONE launch each -- the user
+ * and the item denoiser of HGDM.cal_loss (DiffGraph-Rec/Model.py:96-97).  Fields as the arguments
+ * of the single-pair entry points; the forward reads the first block, the backward also the second.
+ * d_target_add (nullable): a [n][64] table added into d_target, for a gradient that reached
+ * `target` by another route (Model.py:103-104 adds the denoiser output to the same embeddings the
+ * loss compares it with).  n_tasks <= 4. */
+typedef struct dg_loss_task {
+  const dg_denoiser *dn;
+  const float *time_bias;
+  const float *target, *x_start, *noise;
+  const int64_t *ts;
+  int64_t n;
+  float *out;               /* forward */
+  double *row_loss;
+  const double *g_row_loss; /* backward */
+  const float *g_out, *d_target_add;
+  float *d_x_start, *d_target, *dout_tot, *hid, *dpre, *xn;
+} dg_loss_task;
+
+int dg_diffusion_loss_fwd_batched(const dg_loss_task *tasks, int32_t n_tasks, int32_t n_steps,
+                                  const float *sqrt_ac, const float *sqrt_1mac, const double *loss_w,
+                                  int32_t d, void *stream);
+int dg_diffusion_loss_bwd_batched(const dg_loss_task *tasks, int32_t n_tasks, int32_t n_steps,
+                                  const float *sqrt_ac, const float *sqrt_1mac, const double *loss_w,
+                                  int32_t d, void *stream);
+
 /* a11: weight gradients of the denoiser from the four tables dg_diffusion_loss_bwd wrote and the
  * per-row timesteps -- what autograd records for the three nn.Linear layers of Denoise
  * (DiffGraph-Rec/Model.py:184-191, used at :218-232) under loss.backward() (DiffGraph-Rec/main.py:127):

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Builds profiles/<tag>_traffic.json from rocprofv3 --pmc passes (FETCH_SIZE in one run, WRITE_SIZE in
+another) of bench.py: mean bytes per dispatch of the propagation kernels, FETCH_SIZE doubled (gfx950 tallies
+the 128-B requests of 16-B/lane reads at 64 B), summed per fused layer launch.
+
+    make_traffic_json.py OUT.json  tmall FETCH_DIR WRITE_DIR  [industry FETCH_DIR WRITE_DIR]
+"""
+import csv, glob, json, sys, collections
+
+KERNELS = {"tmall": ["gcn_layer_kernel", "hub_reduce_kernel"],
+           "industry": ["lds_rows_kernel", "window_rows_kernel", "hub_reduce_kernel"]}
+
+
+def means(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+out = {"note": "HBM-side (fabric) bytes per propagation-layer launch from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+               "passes (separate runs of `bench.py --steps 4 --warmup 2 --no-cpu-baseline [--workload industry]`), means over "
+               "all dispatches of the kernel; counter values are KiB; FETCH_SIZE doubled (gfx950 counts 128-B requests as "
+               "64 B for 16-B/lane reads), WRITE_SIZE as reported. Infinity-Cache hits are included in these counters."}
+args = sys.argv[2:]
+for k in range(0, len(args), 3):
+    wl, fd, wd = args[k:k + 3]
+    fm, wm = means(fd, "FETCH_SIZE"), means(wd, "WRITE_SIZE")
+    entry, total = {}, 0.0
+    for kern in KERNELS[wl]:
+        fb = sum(v for n, v in fm.items() if kern in n) * 1024 * 2
+        wb = sum(v for n, v in wm.items() if kern in n) * 1024
+        entry[kern] = {"fetch_bytes": fb, "write_bytes": wb}
+        total += fb + wb
+    entry["traffic_bytes_per_layer_launch"] = total
+    out[wl] = entry
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print(json.dumps(out, indent=1))
