@@ -9,15 +9,20 @@
 // backward pass first writes the per-entry gradients of the three gathered rows and counts, with
 // integer atomics, how many entries name each table row and which comes first; a second launch
 // writes the rows named once directly and, for rows named several times, lets the first entry add
-// the later ones IN BATCH ORDER: no float atomics, no sort, the same bits on every run.
+// the later ones IN BATCH ORDER (their indices come from a few per-row slots filled beside the
+// counts, or, for rows named more often than that, from a scan of the batch): no float atomics, the
+// same bits on every run.
 #include "dg_internal.h"
 
 #include <math.h>
+
+#include <climits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+constexpr int kSlots = 6;       // entries of one table row remembered per row; rows named more often are scanned for
 constexpr int kMaxBatch = 8192;  // the three index lists of a batch sit in LDS as int32: 96 KiB at most
 
 template <int CTRL>
@@ -102,7 +107,8 @@ __global__ __launch_bounds__(256) void head_bwd_entries_kernel(const float *ui, 
                                                                const int64_t *ancs, const int64_t *poss,
                                                                const int64_t *negs, int n_batch, int n_user, int n_rows,
                                                                double batch_div, double reg_coef, const float *entries_f,
-                                                               const double *g, float *scratch, int *tag, int *cnt) {
+                                                               const double *g, float *scratch, int *tag, int *cnt,
+                                                               int *slots) {
   const int b = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   if (b >= n_batch) return;
   const int64_t a = ancs[b], p = poss[b], n = negs[b];
@@ -114,15 +120,16 @@ __global__ __launch_bounds__(256) void head_bwd_entries_kernel(const float *ui, 
   G[((size_t)0 * n_batch + b) * 16 + l] = (r.P - r.N) * ds + r.A * c_reg;
   G[((size_t)1 * n_batch + b) * 16 + l] = r.A * ds + r.P * c_reg;
   G[((size_t)2 * n_batch + b) * 16 + l] = r.A * (-ds) + r.N * c_reg;
-  if (l == 0) {
-    atomicMax(tag + a, n_batch - b);
-    atomicAdd(cnt + a, 1);
-  } else if (l == 1) {
-    atomicMax(tag + n_user + p, 2 * n_batch - b);
-    atomicAdd(cnt + n_user + p, 1);
-  } else if (l == 2) {
-    atomicMax(tag + n_user + n, n_batch - b);
-    atomicAdd(cnt + n_user + n, 1);
+  int *idx32 = reinterpret_cast<int *>(scratch + (size_t)3 * n_batch * DG_D);  // [3][n_batch]: ancs | poss | negs
+  // lanes 0..2 register the entry with its table row: first entry (max), count, and -- in arrival
+  // order, which the scatter kernel undoes by sorting -- the entry index in one of the row's kSlots slots
+  if (l < 3) {
+    const int trow = l == 0 ? (int)a : n_user + (int)(l == 1 ? p : n);
+    const int e = l == 2 ? n_batch + b : b;                 // index in the row's list (ancs; poss then negs)
+    atomicMax(tag + trow, (l == 0 ? n_batch : 2 * n_batch) - e);
+    const int k = atomicAdd(cnt + trow, 1);
+    if (k < kSlots) slots[(size_t)trow * kSlots + k] = e;
+    idx32[l * n_batch + b] = l == 0 ? (int)a : (int)(l == 1 ? p : n);
   }
 }
 
@@ -132,51 +139,63 @@ __global__ __launch_bounds__(256) void head_bwd_entries_kernel(const float *ui, 
 // (as int32) and the entry's group scans its list there, 16 entries per step.
 __global__ __launch_bounds__(256) void head_scatter_kernel(const int64_t *ancs, const int64_t *poss, const int64_t *negs,
                                                            int n_batch, int n_user, const double *g, const float *scratch,
-                                                           const int *tag, const int *cnt, float *d_ui, float *d_out_u,
-                                                           float *d_out_i, double *d_rl_u, double *d_rl_i) {
+                                                           const int *tag, const int *cnt, const int *slots, float *d_ui,
+                                                           float *d_out_u, float *d_out_i, double *d_rl_u, double *d_rl_i) {
   extern __shared__ int idx[];  // [3 * n_batch]: ancs | poss | negs
   const int e_all = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15, q = (threadIdx.x & 63) >> 4;
   const bool valid = e_all < 3 * n_batch;
   const bool user = e_all < n_batch;
   const int e = user ? e_all : e_all - n_batch, m = user ? n_batch : 2 * n_batch;
+  const int *idx32 = reinterpret_cast<const int *>(scratch + (size_t)3 * n_batch * DG_D);  // ancs | poss | negs as int32
   int row = 0, trow = 0, c = 0;
   bool owner = false;
   if (valid) {
-    row = (int)(user ? ancs[e] : (e < n_batch ? poss[e] : negs[e - n_batch]));
+    row = idx32[e_all];
     trow = user ? row : n_user + row;
     c = cnt[trow];
     owner = c == 1 || m - tag[trow] == e;  // the only entry naming this row, or the first of several
   }
-  const bool scan = owner && c > 1;
+  const bool scan = owner && c > kSlots;  // more entries than slots: look for them in the list itself
   if (__syncthreads_or(scan)) {
-    for (int i = threadIdx.x; i < 3 * n_batch; i += 256)
-      idx[i] = (int)(i < n_batch ? ancs[i] : (i < 2 * n_batch ? poss[i - n_batch] : negs[i - 2 * n_batch]));
+#pragma unroll 4
+    for (int i = threadIdx.x; i < 3 * n_batch; i += 256) idx[i] = idx32[i];
     __syncthreads();
   }
   if (!owner) return;  // (whole groups leave)
   const f32x4 *G = reinterpret_cast<const f32x4 *>(scratch) + (user ? (size_t)0 : (size_t)n_batch * 16);
   f32x4 acc = G[(size_t)e * 16 + l];
   int n_loss = user || e < n_batch ? 1 : 0;  // entries that carry a diffusion-loss row: ancs, poss
-  if (scan) {
-    const int *list = user ? idx : idx + n_batch;
-    int left = c - 1;
-    for (int j0 = (e + 1) & ~15; left > 0 && j0 < m; j0 += 128) {  // eight 16-entry chunks per step
-      bool hit[8];
+  if (c > 1 && !scan) {
+    // the row's entries from its slots, put in ascending order (they were stored in arrival order)
+    int s[kSlots];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = j0 + 16 * u + l;
-        hit[u] = j > e && j < m && list[j] == row;
+    for (int k = 0; k < kSlots; ++k) s[k] = k < c ? slots[(size_t)trow * kSlots + k] : INT_MAX;
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i)
+#pragma unroll
+      for (int k = 0; k + 1 < kSlots - i; ++k) {
+        const int lo = min(s[k], s[k + 1]), hi = max(s[k], s[k + 1]);
+        s[k] = lo; s[k + 1] = hi;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        unsigned mask = (unsigned)(__ballot(hit[u]) >> (16 * q)) & 0xffffu;
-        while (mask) {
-          const int jj = j0 + 16 * u + __builtin_ctz(mask);
-          mask &= mask - 1;
-          acc += G[(size_t)jj * 16 + l];
-          n_loss += (user || jj < n_batch) ? 1 : 0;
-          --left;
-        }
+    for (int k = 1; k < kSlots; ++k)   // s[0] == e, the first entry
+      if (k < c) {
+        acc += G[(size_t)s[k] * 16 + l];
+        n_loss += (user || s[k] < n_batch) ? 1 : 0;
+      }
+  } else if (scan) {
+    const int *list = user ? idx : idx + n_batch;
+    int left = c - 1;
+    for (int j0 = (e + 1) & ~15; left > 0 && j0 < m; j0 += 16) {
+      const int j = j0 + l;
+      const bool hit = j > e && j < m && list[j] == row;
+      unsigned mask = (unsigned)(__ballot(hit) >> (16 * q)) & 0xffffu;
+      while (mask) {
+        const int jj = j0 + __builtin_ctz(mask);
+        mask &= mask - 1;
+        acc += G[(size_t)jj * 16 + l];
+        n_loss += (user || jj < n_batch) ? 1 : 0;
+        --left;
       }
     }
   }
@@ -224,9 +243,9 @@ extern "C" int dg_rec_head_bwd(const float *ui, const float *out_u, const float 
   if (((uintptr_t)d_ui | (uintptr_t)d_out_u | (uintptr_t)d_out_i | (uintptr_t)scratch) & 15)
     return dg_fail(DG_ERR_ARG, "dg_rec_head_bwd: gradient tables and scratch must be 16-byte aligned");
   const int n_rows = n_user + n_item;
-  int *tag = row_tags, *cnt = row_tags + n_rows;
+  int *tag = row_tags, *cnt = row_tags + n_rows, *slots = row_tags + 2 * (size_t)n_rows;
   hipLaunchKernelGGL(head_bwd_entries_kernel, dim3((n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ui, out_u, out_i,
-                     ancs, poss, negs, n_batch, n_user, n_rows, batch_div, reg_coef, entries_f, g, scratch, tag, cnt);
+                     ancs, poss, negs, n_batch, n_user, n_rows, batch_div, reg_coef, entries_f, g, scratch, tag, cnt, slots);
   static bool attr_set = false;  // more than 64 KiB of dynamic LDS has to be opted into once
   if (!attr_set) {
     DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -235,7 +254,7 @@ extern "C" int dg_rec_head_bwd(const float *ui, const float *out_u, const float 
   }
   hipLaunchKernelGGL(head_scatter_kernel, dim3((3 * n_batch + 15) / 16), dim3(256), 3 * (size_t)n_batch * sizeof(int),
                      (hipStream_t)stream, ancs, poss, negs,
-                     n_batch, n_user, g, scratch, tag, cnt, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
+                     n_batch, n_user, g, scratch, tag, cnt, slots, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
   DG_HIP(hipGetLastError());
   return 0;
 }
