@@ -377,6 +377,19 @@ int dg_eval_metrics(const int32_t *top_idx, int32_t n_test, int32_t k, const int
                     const int32_t *tst_rowptr, const int32_t *tst_col, const double *inv_log2,
                     const double *max_dcg, double *recall, double *ndcg, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Negative sampling.  Replaces PairwiseTrnData.negSampling (DiffGraph-Rec/DataHandler.py:282-289):
+ * for pair p with user rows[p], negs[p] = an item id drawn uniformly from [0, n_item) and re-drawn
+ * while the user has a training interaction with it (training CSR over users as in dg_eval_topk:
+ * DEVICE int32 trn_rowptr[n_user+1], trn_col[] ascending inside a row).  rows, negs: DEVICE
+ * int32[n_pairs].  The draws are a pure function of (seed, p): the reference draws from numpy's
+ * global generator instead, so only the distribution is comparable.  negs[p] = -1 for a user who
+ * has interacted with every item (the reference would not return).
+ * ---------------------------------------------------------------------------------- */
+int dg_neg_sampling(const int32_t *trn_rowptr, const int32_t *trn_col, const int32_t *rows,
+                    int64_t n_pairs, int32_t n_user, int32_t n_item, uint64_t seed, int32_t *negs,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

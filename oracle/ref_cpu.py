@@ -333,3 +333,22 @@ def test_epoch(usr_emb: torch.Tensor, item_emb: torch.Tensor, trn_u: np.ndarray,
     num = len(users)
     return {"Recall": ep_recall / num, "NDCG": ep_ndcg / num, "users": users, "top_locs": np.concatenate(tops),
             "recall_per_user": np.concatenate(recs), "ndcg_per_user": np.concatenate(nds)}
+
+
+# --------------------------------------------------------------------------------------
+# N3: negative sampling -- PairwiseTrnData.negSampling DataHandler.py:282-289
+# --------------------------------------------------------------------------------------
+def neg_sampling(rows: np.ndarray, cols: np.ndarray, n_item: int, rng: np.random.Generator) -> np.ndarray:
+    """One negative per training pair: draw item ids uniformly until the (user, item) pair is not a
+    training interaction.  The reference draws from numpy's global generator (np.random.randint);
+    a Generator is passed here so that tests are repeatable -- only the distribution is comparable."""
+    seen = set(zip(rows.tolist(), cols.tolist()))      # coomat.todok() membership
+    negs = np.zeros(len(rows), dtype=np.int32)
+    for i in range(len(rows)):
+        u = int(rows[i])
+        while True:
+            i_neg = int(rng.integers(n_item))
+            if (u, i_neg) not in seen:
+                break
+        negs[i] = i_neg
+    return negs

@@ -113,3 +113,52 @@ def test_eval_tmall_size_sample_against_oracle():
     scores = (torch.mm(usr[T(su).long()].double(), itm.double().t()) * (1 - m) - m * 1e8).numpy()
     _, want = torch.topk(T(scores), k)
     check_top_lists(top_h[sample], vals_h[sample], want.numpy(), scores, "tmall sample")
+
+
+# ------------------------------------------------------------------------------ N3: negative sampling
+def test_neg_sampling_properties_and_distribution():
+    """PairwiseTrnData.negSampling (DiffGraph-Rec/DataHandler.py:282-289): every negative is in range and not a
+    training item of its user; the same seed gives the same draws, another seed others; per user the negatives
+    are uniform over the items the user has not interacted with, like the oracle's (the reference draws from
+    numpy's global generator, so the streams themselves cannot be compared)."""
+    from diffgraph_amd.sampling import PairwiseTrnData
+    nu, ni = 40, 64
+    u, i = dgdata.synth_interactions(nu, ni, 900, 3)
+    keep = u >= 2
+    # user 0 has interacted with all items but three; user 1 with every item
+    u = np.concatenate([u[keep], np.zeros(ni - 3, np.int32), np.ones(ni, np.int32)])
+    i = np.concatenate([i[keep], np.arange(3, ni, dtype=np.int32), np.arange(ni, dtype=np.int32)])
+    train = set(zip(u.tolist(), i.tolist()))
+    ds = PairwiseTrnData(coo(u, i, nu, ni), seed=7)
+    reps = 300
+    draws = []
+    for _ in range(reps):                                        # one launch per "epoch", a new stream each
+        ds.negSampling()
+        draws.append(ds.negs)
+    negs, uu = np.concatenate(draws), np.tile(u, reps)
+    ok = uu != 1
+    assert (negs[~ok] == -1).all()
+    assert ((negs[ok] >= 0) & (negs[ok] < ni)).all()
+    assert not any((int(a), int(b)) in train for a, b in zip(uu[ok][:20000], negs[ok][:20000]))
+    assert set(negs[uu == 0].tolist()) == {0, 1, 2}
+    ds2 = PairwiseTrnData(coo(u, i, nu, ni), seed=7)
+    ds2.negSampling()
+    np.testing.assert_array_equal(ds2.negs, draws[0])             # same seed, same epoch: same draws
+    assert (draws[1][u != 1] != draws[0][u != 1]).mean() > 0.5    # the next epoch draws afresh
+    # distribution: chi-square of each user's negatives against uniform over its free items, and the same
+    # statistic for the oracle's sampler on the same pairs
+    sub = np.isin(uu, [2, 3, 4, 5])
+    on = O.neg_sampling(uu[sub], np.tile(i, reps)[sub], ni, np.random.default_rng(1))
+    for user in (2, 3, 4, 5):
+        free = np.array([it for it in range(ni) if (user, it) not in train])
+        for name, sample in (("kernel", negs[uu == user]), ("oracle", on[uu[sub] == user])):
+            counts = np.array([(sample == it).sum() for it in free], dtype=np.float64)
+            exp = counts.sum() / len(free)
+            chi2 = ((counts - exp) ** 2 / exp).sum()
+            assert chi2 < len(free) + 6 * np.sqrt(2 * len(free)), f"{name} user {user}: chi2 {chi2} over {len(free)} items"
+    # batches: every pair once, shuffled, as int64 triples
+    seen = 0
+    for ancs, poss, ngs in ds.batches(4096):
+        assert ancs.dtype == torch.int64 and ancs.is_cuda and len(ancs) == len(poss) == len(ngs)
+        seen += len(ancs)
+    assert seen == len(ds)
