@@ -109,6 +109,10 @@ SIGNATURES = {
     "dg_eval_metrics": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
     "dg_neg_sampling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p,
                                   C.c_void_p]),
+    "dg_spgemm_bitmap_words": (C.c_int32, [C.c_int32]),
+    "dg_spgemm_pattern_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dg_spgemm_pattern_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dg_rec_head_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 4),
     "dg_rec_head_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 10),
 }

@@ -390,6 +390,23 @@ int dg_neg_sampling(const int32_t *trn_rowptr, const int32_t *trn_col, const int
                     int64_t n_pairs, int32_t n_user, int32_t n_item, uint64_t seed, int32_t *negs,
                     void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Meta-path composition.  Replaces Hc = Q1.dot(Q2); Hc = (Hc != 0) of
+ * DiffGraph_NC/DataHandler.py:158-161 (scipy on the host): the PATTERN of the product of two CSR
+ * patterns A [n_rows x n_mid] and B [n_mid x n_cols] (DEVICE int32 rowptr / column arrays; values do
+ * not matter -- the reference's mixture weights are softmax outputs, all positive).
+ * dg_spgemm_pattern_rows writes one bitmap of dg_spgemm_bitmap_words(n_cols) uint32 words per output
+ * row (bit c of the row = column c present) and the row's entry count; the caller forms
+ * c_rowptr = exclusive prefix sum of row_nnz, and dg_spgemm_pattern_fill expands the bitmaps into
+ * ascending column ids.  n_cols <= 262144.
+ * ---------------------------------------------------------------------------------- */
+int32_t dg_spgemm_bitmap_words(int32_t n_cols);
+int dg_spgemm_pattern_rows(const int32_t *a_rowptr, const int32_t *a_col, int32_t n_rows,
+                           const int32_t *b_rowptr, const int32_t *b_col, int32_t n_mid, int32_t n_cols,
+                           uint32_t *bitmap, int32_t *row_nnz, void *stream);
+int dg_spgemm_pattern_fill(const uint32_t *bitmap, int32_t n_rows, int32_t n_cols,
+                           const int32_t *c_rowptr, int32_t *c_col, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -352,3 +352,37 @@ def neg_sampling(rows: np.ndarray, cols: np.ndarray, n_item: int, rng: np.random
                 break
         negs[i] = i_neg
     return negs
+
+
+# --------------------------------------------------------------------------------------
+# N2: meta-path composition -- DiffGraph_NC/DataHandler.py:91-165 (LoadData, option B)
+# --------------------------------------------------------------------------------------
+def dblp_global_mats(ap: np.ndarray, pc: np.ndarray, pt: np.ndarray, counts):
+    """The six global relation matrices of DataHandler.py:91-116 (A->P, P->A, C->P, P->C, P->T, T->P on a
+    common node numbering authors | papers | conferences | terms), all values 1."""
+    import scipy.sparse as sp
+    NA, NP, NC, NT = (int(v) for v in counts)
+    off_A, off_P, off_C, off_T = 0, NA, NA + NP, NA + NP + NC
+    n_tot = NA + NP + NC + NT
+    def make_global(rows, cols, src, dst):
+        return sp.coo_matrix((np.ones(len(rows), np.float32), (rows + src, cols + dst)), shape=(n_tot, n_tot))
+    return [make_global(ap[:, 0], ap[:, 1], off_A, off_P), make_global(ap[:, 1], ap[:, 0], off_P, off_A),
+            make_global(pc[:, 1], pc[:, 0], off_C, off_P), make_global(pc[:, 0], pc[:, 1], off_P, off_C),
+            make_global(pt[:, 0], pt[:, 1], off_P, off_T), make_global(pt[:, 1], pt[:, 0], off_T, off_P)]
+
+
+def metapath_he_adjs(global_mats, alpha1: np.ndarray, alpha2: np.ndarray, n_target: int):
+    """DataHandler.py:150-165: per channel Q1 = sum_e alpha1[c,e] G_e, Q2 likewise, Hc = Q1.dot(Q2),
+    binarised, sliced to the first n_target rows and columns (scipy CSR, values 1)."""
+    out = []
+    for c in range(alpha1.shape[0]):
+        Q1 = sum(global_mats[e] * alpha1[c, e] for e in range(len(global_mats)))
+        Q2 = sum(global_mats[e] * alpha2[c, e] for e in range(len(global_mats)))
+        Hc = Q1.dot(Q2)
+        Hc = (Hc != 0).astype(np.float32)
+        Haa = Hc.tocsr()[:n_target, :n_target]
+        Haa.data[:] = 1.0
+        Haa.eliminate_zeros()
+        Haa.sort_indices()
+        out.append(Haa)
+    return out

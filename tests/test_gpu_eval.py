@@ -162,3 +162,66 @@ def test_neg_sampling_properties_and_distribution():
         assert ancs.dtype == torch.int64 and ancs.is_cuda and len(ancs) == len(poss) == len(ngs)
         seen += len(ancs)
     assert seen == len(ds)
+
+
+# ------------------------------------------------------------------------------ N2: meta-path composition
+def _pattern_sig(m):
+    m = m.tocsr()
+    m.sort_indices()
+    deg = np.diff(m.indptr).astype(np.int64)
+    cs = np.add.reduceat(np.append(m.indices.astype(np.int64), 0), m.indptr[:-1]) * (deg > 0)
+    cx = np.array([np.bitwise_xor.reduce(m.indices[m.indptr[r]: m.indptr[r + 1]].astype(np.int64)) if deg[r] else 0
+                   for r in range(m.shape[0])])
+    return deg, cs, cx
+
+
+def test_metapath_composition_dblp_golden():
+    """Device boolean SpGEMM against the matrices the reference ships (apa.npz, apcpa.npz signatures), the oracle's
+    scipy composition (APTPA, 7 M entries, 43 % dense) and the as-coded channel graphs of LoadData."""
+    from diffgraph_amd import metapath as mp
+    from tests.test_oracle_golden import _dblp_graphs
+    g, fx = load("dblp_graph.npz"), load("dblp_metapaths.npz")
+    NA, NP, NC, NT = (int(v) for v in g["counts"])
+    mk = lambda e, shape: sp.coo_matrix((np.ones(len(e), np.float32), (e[:, 0], e[:, 1])), shape=shape).tocsr()
+    AP, PC, PT = mk(g["ap"], (NA, NP)), mk(g["pc"], (NP, NC)), mk(g["pt"], (NP, NT))
+    D = mp.DevicePattern.from_scipy
+    apa = mp.compose([D(AP), D(AP.T)])
+    apcpa = mp.compose([D(AP), D(PC), D(PC.T), D(AP.T)])
+    aptpa = mp.compose([D(AP), D(PT), D(PT.T), D(AP.T)])
+    for name, pat in (("apa", apa), ("apcpa", apcpa)):
+        deg, cs, cx = _pattern_sig(pat.to_scipy())
+        assert pat.nnz == int(fx[name + "_nnz"][0])
+        np.testing.assert_array_equal(deg, fx[name + "_deg"])
+        np.testing.assert_array_equal(cs, fx[name + "_colsum"])
+        np.testing.assert_array_equal(cx, fx[name + "_colxor"])
+    _, _, _, want_aptpa, _ = _dblp_graphs()
+    got = aptpa.to_scipy()
+    assert got.nnz == want_aptpa.nnz == 7043571 and (got != want_aptpa).nnz == 0
+    # LoadData option B: three channels of mixed relations -> author x author graphs
+    mats = O.dblp_global_mats(g["ap"], g["pc"], g["pt"], g["counts"])
+    rng = np.random.default_rng(0)
+    a1 = torch.softmax(T(rng.standard_normal((3, 6)).astype(np.float32)), 1).numpy()
+    a2 = torch.softmax(T(rng.standard_normal((3, 6)).astype(np.float32)), 1).numpy()
+    graphs = mp.compose_he_adjs(mats, a1, a2, NA)
+    want = O.metapath_he_adjs(mats, a1, a2, NA)
+    for gr, w in zip(graphs, want):
+        rowptr, col = gr.csr()           # CSR by destination of the edges row -> col
+        wt = w.T.tocsr(); wt.sort_indices()
+        np.testing.assert_array_equal(rowptr, wt.indptr)
+        np.testing.assert_array_equal(col, wt.indices)
+
+
+def test_spgemm_pattern_ragged_against_scipy():
+    from diffgraph_amd import metapath as mp
+    rng = np.random.default_rng(3)
+    for (m, k, n, da, db) in [(1, 1, 1, 1.0, 1.0), (37, 50, 33, 0.1, 0.2), (300, 5, 4100, 0.5, 0.3), (129, 700, 65, 0.02, 0.0),
+                              (64, 64, 262144, 0.05, 0.0002)]:
+        A = sp.random(m, k, density=da, random_state=rng, format="csr", dtype=np.float32)
+        B = sp.random(k, n, density=db, random_state=rng, format="csr", dtype=np.float32)
+        got = mp.spgemm_pattern(mp.DevicePattern.from_scipy(A), mp.DevicePattern.from_scipy(B)).to_scipy()
+        want = ((A != 0).astype(np.float32) @ (B != 0).astype(np.float32) != 0).astype(np.float32).tocsr()
+        want.sort_indices()
+        np.testing.assert_array_equal(got.indptr, want.indptr)
+        np.testing.assert_array_equal(got.indices, want.indices)
+    with pytest.raises(dg.DiffGraphHipError):
+        mp.spgemm_pattern(mp.DevicePattern.from_scipy(sp.eye(4, format="csr")), mp.DevicePattern.from_scipy(sp.eye(4, 300000, format="csr")))

@@ -187,3 +187,33 @@ def test_eval_oracle_matches_reference_test_epoch():
     np.testing.assert_array_equal(r["recall_per_user"], fx["recall_per_user"])
     np.testing.assert_array_equal(r["ndcg_per_user"], fx["ndcg_per_user"])
     np.testing.assert_array_equal(np.array([r["Recall"], r["NDCG"]]), fx["metrics"])
+
+
+# ------------------------------------------------------------------------------ N2: meta-path composition
+def _sig(m):
+    m = m.tocsr()
+    m.sort_indices()
+    deg = np.diff(m.indptr).astype(np.int64)
+    cs = np.add.reduceat(np.append(m.indices.astype(np.int64), 0), m.indptr[:-1]) * (deg > 0)
+    cx = np.array([np.bitwise_xor.reduce(m.indices[m.indptr[r]: m.indptr[r + 1]].astype(np.int64)) if deg[r] else 0
+                   for r in range(m.shape[0])])
+    return deg, cs, cx
+
+
+def test_metapath_oracle_matches_shipped_matrices():
+    """The oracle's composition (DiffGraph_NC/DataHandler.py:147-165) reproduces the author x author matrices the
+    reference ships: APA as the as-coded 2-hop product of the mixed relations, APCPA as the chain AP.PC.CP.PA."""
+    import scipy.sparse as sp
+    g, fx = load("dblp_graph.npz"), load("dblp_metapaths.npz")
+    NA = int(g["counts"][0])
+    mats = O.dblp_global_mats(g["ap"], g["pc"], g["pt"], g["counts"])
+    alpha = np.full((3, 6), 1.0 / 6, dtype=np.float32)          # any positive mixture gives the same pattern
+    for h in O.metapath_he_adjs(mats, alpha, alpha, NA):
+        deg, cs, cx = _sig(h)
+        assert h.nnz == int(fx["apa_nnz"][0])
+        np.testing.assert_array_equal(deg, fx["apa_deg"]); np.testing.assert_array_equal(cs, fx["apa_colsum"])
+        np.testing.assert_array_equal(cx, fx["apa_colxor"])
+    _, _, apcpa, _, _ = _dblp_graphs()
+    deg, cs, cx = _sig(apcpa)
+    np.testing.assert_array_equal(deg, fx["apcpa_deg"]); np.testing.assert_array_equal(cs, fx["apcpa_colsum"])
+    np.testing.assert_array_equal(cx, fx["apcpa_colxor"])

@@ -420,12 +420,44 @@ def gen_eval():
     print("rec_eval.npz:", len(fx), "arrays; test users", len(users), "Recall/NDCG", ret)
 
 
+# --------------------------------------------------------------------------------------
+# NC meta-path matrices the reference ships (data files, not code)
+# --------------------------------------------------------------------------------------
+def pattern_signature(m):
+    """Per-row entry count, sum and xor of the column ids of a CSR pattern: a compact stand-in for the
+    matrix (a 4057 x 4057 pattern with 5 M entries becomes three 4057-vectors)."""
+    m = m.tocsr()
+    m.sort_indices()
+    deg = np.diff(m.indptr).astype(np.int64)
+    colsum = np.zeros(m.shape[0], np.int64)
+    colxor = np.zeros(m.shape[0], np.int64)
+    for r in range(m.shape[0]):
+        c = m.indices[m.indptr[r]: m.indptr[r + 1]].astype(np.int64)
+        colsum[r] = c.sum()
+        colxor[r] = np.bitwise_xor.reduce(c) if len(c) else 0
+    return deg, colsum, colxor
+
+
+def gen_metapath():
+    """Signatures of the author x author meta-path matrices the reference ships beside its DBLP edge lists
+    (DiffGraph_NC/data/DBLP/apa.npz, apcpa.npz; scipy .npz, loaded without pickle)."""
+    import scipy.sparse as sp
+    fx = {}
+    for name in ("apa", "apcpa"):
+        m = sp.load_npz(os.path.join(REF, "DiffGraph_NC", "data", "DBLP", name + ".npz"))
+        deg, cs, cx = pattern_signature(m != 0)
+        fx[name + "_deg"], fx[name + "_colsum"], fx[name + "_colxor"] = deg, cs, cx
+        fx[name + "_nnz"] = np.array([int(deg.sum())])
+    np.savez_compressed(os.path.join(OUT, "dblp_metapaths.npz"), **fx)
+    print("dblp_metapaths.npz:", {k: int(v[0]) for k, v in fx.items() if k.endswith("_nnz")})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "nc", "eval"]
+    which = sys.argv[1:] or ["rec", "nc", "eval", "metapath"]
     if len(which) == 1:
-        {"rec": gen_rec, "nc": gen_nc, "eval": gen_eval}[which[0]]()
+        {"rec": gen_rec, "nc": gen_nc, "eval": gen_eval, "metapath": gen_metapath}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
             subprocess.run([sys.executable, os.path.abspath(__file__), w], check=True)
