@@ -2,6 +2,7 @@
 """bench.py -- DiffGraph hot path on MI355X: SpMM edges/s + achieved HBM GB/s per propagation layer.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tmall|ijcai|retail_rocket|industry]
+    python bench.py --workload eval_tmall|eval_ijcai|negsample_tmall|metapath_dblp     (neighbouring stages)
 
 One JSON line on stdout (rank 0).  A "step" is one pass of the hot path over one synthetic
 batch: HGDM.cal_loss -- (1+B)*L fused propagation launches, q_sample + denoiser + SNR loss for
@@ -142,6 +143,17 @@ def main():
         return
 
     workload = args.workload or "tmall"
+    if workload.startswith(("eval_", "negsample_", "metapath")):
+        # the stages either side of the propagation path (evaluation, sampling, graph construction)
+        from diffgraph_amd import bench_next
+        if workload.startswith("eval_"):
+            res = bench_next.bench_eval(workload[5:], args.steps, args.warmup, not args.no_cpu_baseline)
+        elif workload.startswith("negsample_"):
+            res = bench_next.bench_negsample(workload[10:], args.steps, args.warmup, not args.no_cpu_baseline)
+        else:
+            res = bench_next.bench_metapath(args.steps, args.warmup, not args.no_cpu_baseline)
+        print(json.dumps(res))
+        return
     wl, graphs, model = build_rec(workload, device)
     n = wl.n
     gen = torch.Generator().manual_seed(1)
