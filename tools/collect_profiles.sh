@@ -15,6 +15,21 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_tmall_$c -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_tmall_$c.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_industry_$c -o p -- python $R/bench.py --workload industry --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_industry_$c.log 2>&1
 done
+# SQ / TA / L2 counters of the layer kernel (forward propagation only, scratch/layer_bench.py)
+i=0
+: > $O/pmc_gcn_layer.txt
+for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum" "GRBM_GUI_ACTIVE MeanOccupancyPerCU MemUnitStalled" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_layer_$i -o p -- python $R/scratch/layer_bench.py tmall 0,0 > $O/pmc_layer_$i.log 2>&1
+  echo "## rocprofv3 --pmc $c -- python scratch/layer_bench.py tmall 0,0   (per-dispatch means; FETCH/WRITE_SIZE in KiB)" >> $O/pmc_gcn_layer.txt
+  python $R/tools/pmc_summary.py $O/pmc_layer_$i gcn_layer >> $O/pmc_gcn_layer.txt
+  python $R/tools/pmc_summary.py $O/pmc_layer_$i hub_reduce >> $O/pmc_gcn_layer.txt
+done
+for w in eval_tmall eval_ijcai negsample_tmall metapath_dblp; do
+  timeout -k 10 200 python $R/bench.py --workload $w --steps 10 --warmup 3 > $O/${w}_bench.json 2> $O/${w}_bench.err
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_eval -o p -- python $R/bench.py --workload eval_tmall --steps 10 --warmup 3 --no-cpu-baseline > $O/ks_eval.log 2>&1
+cp $O/ks_eval/p_kernel_stats.csv $O/eval_tmall_kernel_stats.csv
 python $R/tools/make_traffic_json.py $O/traffic.json tmall $O/pmc_tmall_FETCH_SIZE $O/pmc_tmall_WRITE_SIZE industry $O/pmc_industry_FETCH_SIZE $O/pmc_industry_WRITE_SIZE > /dev/null
 cp $O/ks_tmall/p_kernel_stats.csv $O/tmall_train_step_kernel_stats.csv
 cp $O/ks_industry/p_kernel_stats.csv $O/industry_1gpu_kernel_stats.csv
