@@ -2,6 +2,7 @@
 """bench.py -- DiffGraph hot path on MI355X: SpMM edges/s + achieved HBM GB/s per propagation layer.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tmall|ijcai|retail_rocket|industry]
+    python bench.py --workload predict_ijcai|nc_dblp                                   (the other BASELINE configs)
     python bench.py --workload eval_tmall|eval_ijcai|negsample_tmall|metapath_dblp     (neighbouring stages)
 
 One JSON line on stdout (rank 0).  A "step" is one pass of the hot path over one synthetic
@@ -143,11 +144,15 @@ def main():
         return
 
     workload = args.workload or "tmall"
-    if workload.startswith(("eval_", "negsample_", "metapath")):
+    if workload.startswith(("eval_", "negsample_", "metapath", "predict_", "nc_dblp")):
         # the stages either side of the propagation path (evaluation, sampling, graph construction)
         from diffgraph_amd import bench_next
         if workload.startswith("eval_"):
             res = bench_next.bench_eval(workload[5:], args.steps, args.warmup, not args.no_cpu_baseline)
+        elif workload.startswith("predict_"):
+            res = bench_next.bench_predict(workload[8:], args.steps, args.warmup, not args.no_cpu_baseline)
+        elif workload.startswith("nc_dblp"):
+            res = bench_next.bench_nc_dblp(args.steps, args.warmup, not args.no_cpu_baseline)
         elif workload.startswith("negsample_"):
             res = bench_next.bench_negsample(workload[10:], args.steps, args.warmup, not args.no_cpu_baseline)
         else:

@@ -154,3 +154,112 @@ def bench_metapath(steps: int, warmup: int, cpu_baseline: bool):
         res["cpu_baseline"] = {"value": n * nnz_out / el, "unit": "entries/s", "cores": 1, "kind": "port",
                                "sample": f"{n} x the three compositions with scipy sparse products, {el:.1f} s"}
     return res
+
+
+def bench_predict(workload: str, steps: int, warmup: int, cpu_baseline: bool):
+    """HGDM.predict (DiffGraph-Rec/Model.py:112-118): forward propagation + the 200-step reverse diffusion loop
+    for every user and item row; the roofline entry is the reverse loop's (fp32 MFMA: 200 x 17 408 FLOP per row)."""
+    from types import SimpleNamespace
+    from oracle import ref_cpu as O
+    from . import CSRGraph, rec
+    dev = torch.device("cuda", torch.cuda.current_device())
+    wl = dgdata.rec_workload(workload)
+    graphs = [CSRGraph.from_bipartite(u, i, wl.n_user, wl.n_item) for (u, i) in [wl.target] + wl.behaviours]
+    handler = SimpleNamespace(userNum=wl.n_user, itemNum=wl.n_item, target_adj=graphs[0], behavior_mats=graphs[1:])
+    torch.manual_seed(3)
+    model = rec.HGDM(handler, device=dev).eval()
+    model.set_embeddings(torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)).to(dev),
+                         torch.from_numpy(dgdata.xavier_uniform(wl.n_item, 64, seed=1)).to(dev))
+    with torch.no_grad():
+        wall_ms, _ = _timed(model.predict, steps, warmup)
+        ui, het = model.propagate(model.embedding_table)
+        dp = model.diffusion_process
+        pairs = [(model.usr_denoiser, het[: wl.n_user]), (model.item_denoiser, het[wl.n_user:])]
+        _, loop_ms = _timed(lambda: dp.p_sample_many(pairs, model.args.sampling_steps), steps, warmup)
+    n = wl.n
+    flop = float(n) * dp.steps * 17408.0
+    nnz = [g.num_edges() for g in graphs]
+    res = {"metric": "HGDM.predict: embedding rows/sec through propagation + 200-step reverse diffusion", "value": n / (wall_ms * 1e-3),
+           "unit": "rows/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": wall_ms, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"predict_{workload}: {wl.note}", "n_user": wl.n_user, "n_item": wl.n_item,
+                      "directed_edges_per_graph": nnz, "layers": model.n_layers, "diffusion_steps": dp.steps,
+                      "edges_per_s": 2.0 * sum(nnz) / (wall_ms * 1e-3)},
+           "roofline": {"bound": "mfma", "achieved": flop / (loop_ms * 1e-3) / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": flop / (loop_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "denoise_kernel<MODE_PSAMPLE> (both denoisers, one launch)", "flop_per_launch": flop,
+                        "ms_per_launch": loop_ms}}
+    if cpu_baseline:
+        n_s = 512
+        tab = O.DiffusionTables(noise_scale=1e-4, noise_min=1e-4, noise_max=1e-3, steps=dp.steps)
+        dn = model.usr_denoiser
+        w = O.DenoiseWeights(*[t.detach().cpu() for t in (dn.emb_layer.weight, dn.emb_layer.bias, dn.in_layers[0].weight,
+                                                          dn.in_layers[0].bias, dn.out_layers[0].weight, dn.out_layers[0].bias)])
+        x = het[:n_s].cpu()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 10.0:
+            O.p_sample(tab, w, x, 0)
+            k += 1
+        el = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": k * n_s / el, "unit": "rows/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{k} x the 200-step reverse loop over {n_s} rows (reverse loop only, torch CPU ops as the "
+                                         f"reference's p_sample), {el:.1f} s"}
+    return res
+
+
+def bench_nc_dblp(steps: int, warmup: int, cpu_baseline: bool):
+    """DiffGraph_NC on DBLP (4 057 authors; meta-path graphs APA / APCPA / APTPA composed on the device from the
+    committed edge lists): HGDM.get_allembeds = input projection, 3 x 3 propagation layers, reverse loop, classifier."""
+    import os
+    from oracle import ref_cpu as O
+    from . import nc
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dblp_graph.npz"))
+    NA, NP, NC, NT = (int(v) for v in g["counts"])
+    mk = lambda e, shape: sp.coo_matrix((np.ones(len(e), np.float32), (e[:, 0], e[:, 1])), shape=shape).tocsr()
+    AP, PC, PT = mk(g["ap"], (NA, NP)), mk(g["pc"], (NP, NC)), mk(g["pt"], (NP, NT))
+    D = mp.DevicePattern.from_scipy
+    pats = [mp.compose([D(AP), D(AP.T)]), mp.compose([D(AP), D(PC), D(PC.T), D(AP.T)]), mp.compose([D(AP), D(PT), D(PT.T), D(AP.T)])]
+    from .graph import CSRGraph
+    mats = [p.to_scipy() for p in pats]
+    adjs = [CSRGraph.from_scipy(m) for m in mats]
+    feats = sp.csr_matrix((g["feat_data"], g["feat_indices"], g["feat_indptr"]), shape=tuple(g["feat_shape"]))
+    rowsum = np.array(feats.sum(1)).flatten()
+    with np.errstate(divide="ignore"):
+        r_inv = np.power(rowsum, -1.0)
+    r_inv[np.isinf(r_inv)] = 0.0
+    features = torch.from_numpy(np.asarray(sp.diags(r_inv).dot(feats).todense(), dtype=np.float32))
+    torch.manual_seed(5)
+    model = nc.HGDM(features.shape[1]).eval()
+    fd = features.to(dev)
+    with torch.no_grad():
+        wall_ms, _ = _timed(lambda: model.get_allembeds(adjs, fd), steps, warmup)
+        embed = model.transform_layer(fd)
+        _, prop_ms = _timed(lambda: model.propagate(adjs, embed), steps, warmup)
+    nnz = [m.nnz for m in mats]
+    L = model.args.gcn_layer
+    layer_bytes = sum(4 * e + 1032 * NA for e in nnz)
+    res = {"metric": "DiffGraph_NC get_allembeds: SpMM edges/sec through projection + propagation + reverse diffusion + classifier",
+           "value": L * sum(nnz) / (wall_ms * 1e-3), "unit": "edges/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": wall_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "DBLP edge lists and author features (tests/golden/dblp_graph.npz), random-init weights",
+           "config": {"workload": "nc_dblp: APA / APCPA / APTPA author graphs", "authors": NA, "directed_edges_per_graph": nnz,
+                      "layers": L, "propagation_ms": prop_ms},
+           "roofline": {"bound": "hbm", "achieved": L * layer_bytes / (prop_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": L * layer_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "gcn_layer_kernel + hub_reduce_kernel, 3 layers x 3 graphs",
+                        "bytes_per_launch": layer_bytes, "ms_per_launch": prop_ms / L,
+                        "note": "the 1 MB tables sit in L2: the layers are bound by the L2 gather rate (12 M edges x 256 B per "
+                                "layer), not by HBM"}}
+    if cpu_baseline:
+        T = lambda m: tuple(torch.from_numpy(a.astype(np.int64)) for a in (m.tocoo().row, m.tocoo().col))
+        adj_t = [T(m) for m in mats]
+        w_t, b_t = model.transform_layer.weight.detach().cpu(), model.transform_layer.bias.detach().cpu()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 10.0 and k < 20:
+            O.nc_forward(adj_t, features, w_t, b_t, L)
+            k += 1
+        el = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": k * L * sum(nnz) / el, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{k} x the forward (projection + {L} layers x 3 graphs, index_add_ form), {el:.1f} s"}
+    return res
