@@ -173,8 +173,8 @@ def main():
 
     timer = LayerTimer()
     model.layer_hook = timer
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0, fused=True,
-                           capturable=True)  # DiffGraph-Rec/main.py:117-119
+    import diffgraph_amd as dg
+    opt = dg.optim.Adam(model, lr=1e-3, weight_decay=0)  # DiffGraph-Rec/main.py:117-119
 
     def step():
         # one training step as Coach.trainEpoch runs it (DiffGraph-Rec/main.py:114-128): cal_loss (timesteps

@@ -70,6 +70,9 @@ class _PropagateFn(torch.autograd.Function):
             w[g] = out
         ops.gcn_layer_bwd_batched(tasks)
         # every graph's layer sum starts from e0 (Model.py:57,74): d e0 = sum_g (d_sum_g + G0_g)
+        if getattr(model, "defer_embedding_grad", False):
+            model.embedding_grad_parts = d_sum + w   # diffgraph_amd.optim.Adam adds them up inside its step
+            return None, None
         return ops.sum_tables(d_sum + w), None
 
 

@@ -351,6 +351,18 @@ int dg_rec_head_bwd(const float *ui, const float *out_u, const float *out_i, con
                     double *d_row_loss_i, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Adam step of one table, the gradient given as the n_parts (<= 16) tables whose left-to-right sum
+ * it is (HOST array of DEVICE pointers).  Replaces torch.optim.Adam.step() for the embedding table
+ * (DiffGraph-Rec/main.py:117-119,127-128; amsgrad off) together with the final sum of the backward
+ * pass.  exp_avg / exp_avg_sq: DEVICE moment tables like param; state: DEVICE float[4] whose first
+ * word is the number of steps taken so far (0 before the first call; the call advances it, so a
+ * captured launch steps on every replay).  n_elems % 4 == 0.
+ * ---------------------------------------------------------------------------------- */
+int dg_adam_step(float *param, const float *const *grad_parts_host, int32_t n_parts, float *exp_avg,
+                 float *exp_avg_sq, float *state, int64_t n_elems, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * All-rank evaluation.  Replaces the per-batch body of Coach.testEpoch
  * (DiffGraph-Rec/main.py:153-160) with the dense train-mask rows of AllRankTestData
  * (DiffGraph-Rec/DataHandler.py:268-272):

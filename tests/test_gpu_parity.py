@@ -323,6 +323,35 @@ def test_rec_loss_head_matches_torch_autograd(n_batch):
         assert torch.equal(g.grad, g2.grad)
 
 
+def test_adam_matches_torch_adam_over_steps():
+    """diffgraph_amd.optim.Adam (table kernel fed with the backward pass's gradient parts + torch's Adam for the
+    denoisers) against torch.optim.Adam on an identical model (DiffGraph-Rec/main.py:117-119), five steps."""
+    fx, nu, ni, *_ = tiny_fixture()
+    wl = dgdata.rec_workload("tiny")
+    models = [rec_model(wl, fx), rec_model(wl, fx)]
+    for m in models:
+        m.set_embeddings(dev(fx["user_emb"]), dev(fx["item_emb"]))
+    opts = [dg.optim.Adam(models[0], lr=1e-2), torch.optim.Adam(models[1].parameters(), lr=1e-2, weight_decay=0)]
+    args = [dev(fx[k]) for k in ("cl_ancs", "cl_poss", "cl_negs", "cl_ts_u", "cl_noise_u", "cl_ts_i", "cl_noise_i")]
+    for step in range(5):
+        losses = []
+        for m, o in zip(models, opts):
+            loss = m.cal_loss(*args)[0]
+            o.zero_grad(set_to_none=True)
+            loss.backward()
+            o.step()
+            losses.append(float(loss.detach()))
+        assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[1]), (step, losses)
+    assert models[0].embedding_table.grad is None and models[1].embedding_table.grad is not None
+    for (n0, p0), (n1, p1) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        scale = float(p1.detach().abs().max())
+        np.testing.assert_allclose(p0.detach().cpu().numpy(), p1.detach().cpu().numpy(), rtol=0, atol=2e-5 * scale, err_msg=n0)
+    sd = opts[0].state_dict()
+    o2 = dg.optim.Adam(models[0], lr=1e-2)
+    o2.load_state_dict(sd)
+    assert float(o2.state[0]) == 5.0 and torch.equal(o2.exp_avg, opts[0].exp_avg)
+
+
 # ------------------------------------------------------------------------------ a3 (DBLP)
 @pytest.mark.parametrize("tag", ["coded", "named"])
 def test_nc_dblp_golden(tag):
