@@ -20,7 +20,7 @@ from .layers import DGLLayer, UUGCNLayer  # noqa: F401
 from .diffusion import Denoise, GaussianDiffusion  # noqa: F401
 from . import model_rec as rec  # noqa: F401
 from . import model_nc as nc  # noqa: F401
-from . import data, evaluate, metapath, ops, optim, sampling  # noqa: F401
+from . import data, evaluate, io, metapath, ops, optim, sampling  # noqa: F401
 
 __all__ = ["CSRGraph", "DGLLayer", "UUGCNLayer", "Denoise", "GaussianDiffusion", "rec", "nc", "ops", "data",
            "DiffGraphHipError"]
