@@ -29,6 +29,7 @@ constexpr int kUsersPerBlock = 128;      // 4 wavefronts x 32 users
 constexpr int kTile = 32;                // items per tile
 constexpr int kPitch = 68;               // floats per staged item row (64 + 4: conflict-free ds_read_b128)
 constexpr float kMasked = -1e8f;         // main.py:157
+constexpr int kBuf = 8;                  // parked candidates per lane between two list merges
 
 struct topk_args {
   const float *usr_emb, *item_emb;
@@ -54,6 +55,8 @@ __device__ __forceinline__ int lower_bound(const int32_t *__restrict__ col, int 
 template <int KPAD>
 __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
   __shared__ float tile[2 * kTile * kPitch];
+  __shared__ float bs[kBuf * 256];  // parked scores [slot][thread] ...
+  __shared__ int bi[kBuf * 256];    // ... and their item ids
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
   const int k = a.k;
   const int t_idx = blockIdx.x * kUsersPerBlock + wave * 32 + j;
@@ -72,6 +75,32 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
   int li[KPAD];
 #pragma unroll
   for (int p = 0; p < KPAD; ++p) { ls[p] = p < KPAD - k ? INFINITY : -INFINITY; li[p] = -1; }
+
+  // Scores that beat the list's last entry are parked in a small per-lane buffer (LDS, in the order seen)
+  // and merged into the lists by ALL lanes together whenever some lane's buffer is full: the
+  // compare-and-shift network then runs for 64 lanes at once instead of once per lucky lane.
+  int nb = 0;
+  auto compact = [&]() {
+    for (int b = 0; b < kBuf; ++b) {
+      const bool have = b < nb;
+      const float s = have ? bs[b * 256 + tid] : -INFINITY;
+      const int id = have ? bi[b * 256 + tid] : -1;
+      if (!__any(have)) break;
+      if (s > ls[KPAD - 1]) {
+        // slot p takes its upper neighbour when s beats that one too, s when it beats only slot p's entry
+        bool above = s > ls[KPAD - 2];
+#pragma unroll
+        for (int p = KPAD - 1; p >= 1; --p) {
+          const bool here = p == KPAD - 1 ? true : s > ls[p];
+          ls[p] = above ? ls[p - 1] : (here ? s : ls[p]);
+          li[p] = above ? li[p - 1] : (here ? id : li[p]);
+          if (p >= 2) above = s > ls[p - 2];
+        }
+        if (s > ls[0]) { ls[0] = s; li[0] = id; }
+      }
+    }
+    nb = 0;
+  };
 
   const int tile0 = blockIdx.y * a.tiles_per_split;
   const int n_tiles_all = (a.n_item + kTile - 1) / kTile;
@@ -135,31 +164,27 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
     }
     // the other half-wavefront holds the same user's list over the other items of each tile: nothing
     // below ITS worst entry can be among the user's k best either
-    const float tau_other = __shfl_xor(ls[KPAD - 1], 32);
+    const float tau = ls[KPAD - 1], tau_other = __shfl_xor(tau, 32);
     float best = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) best = fmaxf(best, acc[r]);
-    if (valid && best > ls[KPAD - 1] && best >= tau_other) {
+    if (__any(valid && best > tau && best >= tau_other)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float s = acc[r];
-        if (!(s > ls[KPAD - 1] && s >= tau_other)) continue;  // equal scores: the earlier (lower) item id stays
-        const int id = item0 + 8 * (r >> 2) + 4 * h + (r & 3);
-        // slot p takes its upper neighbour when s beats that one too, s when it beats only slot p's entry
-        bool above = s > ls[KPAD - 2];
-#pragma unroll
-        for (int p = KPAD - 1; p >= 1; --p) {
-          const bool here = p == KPAD - 1 ? true : s > ls[p];
-          ls[p] = above ? ls[p - 1] : (here ? s : ls[p]);
-          li[p] = above ? li[p - 1] : (here ? id : li[p]);
-          if (p >= 2) above = s > ls[p - 2];
+        // equal scores: the earlier (lower) item id stays, so a new one has to be strictly better
+        const bool cand = valid && acc[r] > tau && acc[r] >= tau_other;
+        if (__any(cand && nb >= kBuf)) compact();
+        if (cand) {  // parked; merged into the list at the next compaction
+          bs[nb * 256 + tid] = acc[r];
+          bi[nb * 256 + tid] = item0 + 8 * (r >> 2) + 4 * h + (r & 3);
+          ++nb;
         }
-        if (s > ls[0]) { ls[0] = s; li[0] = id; }
       }
     }
     if (t + 1 < tile1) stage(buf ^ 1, p0, p1);
     __syncthreads();
   }
+  compact();
   if (!valid) return;
   const size_t o = ((size_t)t_idx * 2 * a.n_split + 2 * blockIdx.y + h) * k;
 #pragma unroll
@@ -169,13 +194,13 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
 
 // One wavefront per test user: the k best of its n_cand candidates, by falling score, equal
 // scores by rising item id (k rounds of a wavefront-wide arg-max).
+template <int kPer>  // candidates per lane: n_cand <= 64 * kPer
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict__ cand_score,
                                                          const int32_t *__restrict__ cand_idx, int n_test, int n_cand,
                                                          int k, int32_t *__restrict__ top_idx,
                                                          float *__restrict__ top_score) {
   const int lane = threadIdx.x & 63, u = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (u >= n_test) return;
-  constexpr int kPer = 16;  // candidates per lane (n_cand <= 1024)
   float sc[kPer];
   int ix[kPer];
 #pragma unroll
@@ -278,8 +303,10 @@ extern "C" int dg_eval_topk(const float *usr_emb, const float *item_emb, int32_t
   void (*kern)(const topk_args) = kpad == 8 ? score_topk_kernel<8> : kpad == 16 ? score_topk_kernel<16>
                                   : kpad == 24 ? score_topk_kernel<24> : score_topk_kernel<32>;
   hipLaunchKernelGGL(kern, dim3(tiles, n_split), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(merge_topk_kernel, dim3((n_test + 3) / 4), dim3(256), 0, (hipStream_t)stream, a.cand_score, a.cand_idx,
-                     n_test, 2 * n_split * k, k, top_idx, top_score);
+  const int n_cand = 2 * n_split * k;
+  auto merge = n_cand <= 128 ? merge_topk_kernel<2> : n_cand <= 256 ? merge_topk_kernel<4> : merge_topk_kernel<8>;  // <= 512
+  hipLaunchKernelGGL(merge, dim3((n_test + 3) / 4), dim3(256), 0, (hipStream_t)stream, a.cand_score, a.cand_idx, n_test, n_cand, k,
+                     top_idx, top_score);
   DG_HIP(hipGetLastError());
   return 0;
 }
