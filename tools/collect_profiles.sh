@@ -15,13 +15,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_tmall_$c -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_tmall_$c.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_industry_$c -o p -- python $R/bench.py --workload industry --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_industry_$c.log 2>&1
 done
-# SQ / TA / L2 counters of the layer kernel (forward propagation only, scratch/layer_bench.py)
+# SQ / TA / L2 counters of the layer kernel (forward propagation only, tools/layer_bench.py)
 i=0
 : > $O/pmc_gcn_layer.txt
 for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum" "GRBM_GUI_ACTIVE MeanOccupancyPerCU MemUnitStalled" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_layer_$i -o p -- python $R/scratch/layer_bench.py tmall 0,0 > $O/pmc_layer_$i.log 2>&1
-  echo "## rocprofv3 --pmc $c -- python scratch/layer_bench.py tmall 0,0   (per-dispatch means; FETCH/WRITE_SIZE in KiB)" >> $O/pmc_gcn_layer.txt
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_layer_$i -o p -- python $R/tools/layer_bench.py tmall 0,0 > $O/pmc_layer_$i.log 2>&1
+  echo "## rocprofv3 --pmc $c -- python tools/layer_bench.py tmall 0,0   (per-dispatch means; FETCH/WRITE_SIZE in KiB)" >> $O/pmc_gcn_layer.txt
   python $R/tools/pmc_summary.py $O/pmc_layer_$i gcn_layer >> $O/pmc_gcn_layer.txt
   python $R/tools/pmc_summary.py $O/pmc_layer_$i hub_reduce >> $O/pmc_gcn_layer.txt
 done
