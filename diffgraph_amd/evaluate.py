@@ -65,6 +65,8 @@ def all_rank_topk(usrEmbeds: torch.Tensor, itmEmbeds: torch.Tensor, users: torch
         raise DiffGraphHipError("embedding tables do not match the interaction matrices")
     if users.dtype != torch.int64 or not users.is_cuda or users.dim() != 1:
         raise DiffGraphHipError("users: expected a 1-D int64 GPU tensor")
+    if users.numel() and (int(users.min()) < 0 or int(users.max()) >= data.n_user):
+        raise DiffGraphHipError(f"users must lie in [0,{data.n_user})")
     usrEmbeds, itmEmbeds, users = usrEmbeds.contiguous(), itmEmbeds.contiguous(), users.contiguous()
     lib = _lib.load()
     dev = usrEmbeds.device
