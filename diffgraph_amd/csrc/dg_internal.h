@@ -41,7 +41,7 @@ struct dg_csr {
   int32_t *colidx = nullptr;     // [nnz], ascending inside a row
   float *colscale = nullptr;     // [nnz] degree norm of the gathered node colidx[p]
   int32_t *row_order = nullptr;  // [n]: hub rows, then wave rows, then group rows (each by falling degree)
-  // One 16-word record per node of [slot_begin, slot_begin + n_slots), in node order: words 0..12 the first 13 neighbour ids (-1 = none),
+  // One 16-word record per node of [slot_begin, slot_begin + n_slots), by degree class and node id: words 0..12 the first 13 neighbour ids (-1 = none),
   // word 13 the row id, word 14 its degree -- or -1 when the row is not a group row (summed as a
   // wave or hub row, or not owned by this rank) -- word 15 the colidx position of neighbour 13.
   // One coalesced 64-B read gives a short row everything it needs.
@@ -110,7 +110,6 @@ struct dg_task_dev {
   float *row_norm;       // forward: ||y|| out (NULL: off); backward with DG_BWD_NORM_FEED: ||y|| in
   int32_t n, n_hub, n_wave, n_group, n_seg;  // n_group: head records (dg_csr::n_slots)
   int32_t n_seg_slots, n_gseg_slots;
-  int32_t group_row0;                        // node of head record 0
   int32_t flags;
   float slope;
   int32_t lds_split;      // > 0: rows below it are summed by lds_rows_kernel

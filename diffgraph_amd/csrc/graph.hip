@@ -296,9 +296,8 @@ void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c, c
   };
   lay_out(wave_pieces, 4, c.seg_desc, c.n_seg_slots);
   lay_out(group_pieces, 16, c.gseg_desc, c.n_gseg_slots);
-  // One head record per node, in node order (rows of the other classes, and rows this rank does not own,
-  // carry degree -1 and are skipped): a group then knows its row before the record arrives, and the
-  // epilogue's tables are read and written as consecutive lines.
+  // One head record per node (rows of the other class, and rows this rank does not own, carry degree -1
+  // and are skipped).
   // The records span the owned rows only (a rank of a row-block partition owns one block).
   const int32_t n_nodes = (int32_t)deg.size();
   int32_t lo = 0, hi = n_nodes;
@@ -310,11 +309,24 @@ void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c, c
   c.n_slots = hi - lo;
   c.head.assign((size_t)c.n_slots * 16, -1);
   c.head_scale.assign((size_t)c.n_slots * 16, 0.f);
-  for (int32_t r = lo; r < hi; ++r) {
-    int32_t *hd = &c.head[(size_t)(r - lo) * 16];
+  // Records go in six coarse degree classes, longest rows first, node order inside a class: the four rows
+  // that share a wavefront then issue about the same number of gathers (a wavefront load instruction costs
+  // the same whether one or four of its row groups still have neighbours), while the epilogue's tables
+  // are still walked in long ascending runs.
+  std::vector<int32_t> slot_row;
+  for (int32_t r = lo; r < hi; ++r) slot_row.push_back(r);
+  auto degree_class = [&](int32_t r) {
+    if ((owned && !(*owned)[r]) || deg[r] > group_max) return 6;   // skipped rows last
+    const int32_t d = deg[r];
+    return d > 29 ? 0 : d > 13 ? 1 : d > 8 ? 2 : d > 4 ? 3 : d > 0 ? 4 : 5;
+  };
+  std::stable_sort(slot_row.begin(), slot_row.end(), [&](int32_t a, int32_t b) { return degree_class(a) < degree_class(b); });
+  for (int32_t k = 0; k < c.n_slots; ++k) {
+    const int32_t r = slot_row[k];
+    int32_t *hd = &c.head[(size_t)k * 16];
     hd[13] = r;
     if ((owned && !(*owned)[r]) || deg[r] > group_max) continue;  // hd[14] stays -1
-    float *hs = &c.head_scale[(size_t)(r - lo) * 16];
+    float *hs = &c.head_scale[(size_t)k * 16];
     const int32_t b = c.rowptr[r], d = deg[r];
     for (int32_t j = 0; j < std::min(d, kHead); ++j) {
       hd[j] = c.colidx[b + j];

@@ -11,8 +11,8 @@
 // neighbour rows (1 KiB, four fully used 256-B segments).  A group reads 16 neighbour ids
 // with one coalesced load, then hands them round with DPP row broadcasts (no LDS).  Rows
 // are binned by in-degree on the host:
-//   group rows (deg <= group_max): one group per row, four rows per wavefront, in node order
-//                                  (consecutive rows stream through the epilogue as whole lines);
+//   group rows (deg <= group_max): one group per row, four rows per wavefront, in six degree
+//                                  classes (like lengths share a wavefront), node order inside;
 //   cut rows   (deg >  group_max): the neighbour list is cut by source-node range (8 ranges, one
 //                                  per XCD, so that each XCD's L2 serves one eighth of the source
 //                                  table) and into pieces of <= seg_len neighbours; a piece is
@@ -261,13 +261,14 @@ __device__ __forceinline__ void layer_block(const dg_task_dev &T, int lb) {
       reinterpret_cast<f32x4 *>(T.slab)[(size_t)d.z * (DG_D / 4) + l] = acc;
     }
   } else {
-    // group rows: slot k IS node k, so the epilogue's inputs are asked for together with the head record
-    const int k = (lb - nb_seg - nb_gseg) * 16 + wave * 4 + q, row = T.group_row0 + k;
+    // group rows: four records per wavefront; the record names its row
+    const int k = (lb - nb_seg - nb_gseg) * 16 + wave * 4 + q;
     if (k < T.n_group) {
       const int hv = T.head[(size_t)k * 16 + l];
       const float hs = SCALE ? T.head_scale[(size_t)k * 16 + l] : 0.f;
-      const row_ctx rc = load_row_ctx(T, row, l);
       const int deg = bcast16<14>(hv), tail = bcast16<15>(hv);
+      const int row = bcast16<13>(hv);
+      const row_ctx rc = load_row_ctx(T, row, l);
       if (deg >= 0) {
         const int c = l < 13 ? hv : -1;
         const unsigned lane_off = (unsigned)l * 16u;
@@ -579,7 +580,7 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   o.dinv_row = transpose ? g->dinv_src : g->dinv_dst;
   o.dinv_out = transpose ? g->dinv_dst : g->dinv_src;
   o.x = in.x; o.slab = g->slab; o.e_out = in.e_out; o.acc_in = in.acc_in; o.acc_out = in.acc_out;
-  o.n = g->n; o.n_hub = c.n_hub; o.n_wave = c.n_wave; o.n_group = c.n_slots; o.group_row0 = c.slot_begin; o.n_seg = c.n_seg; o.n_seg_slots = c.n_seg_slots; o.n_gseg_slots = c.n_gseg_slots;
+  o.n = g->n; o.n_hub = c.n_hub; o.n_wave = c.n_wave; o.n_group = c.n_slots; o.n_seg = c.n_seg; o.n_seg_slots = c.n_seg_slots; o.n_gseg_slots = c.n_gseg_slots;
   o.flags = in.flags; o.slope = in.slope;
   o.e_saved = nullptr; o.d_sum = nullptr;
   o.fin_partials = nullptr; o.fin_stride = 0; o.fin_parts = o.fin_row_begin = o.fin_rows = 0;
