@@ -76,6 +76,34 @@ def test_layer_tiny_all_row_classes(group_max, seg_len):
     assert float(y[nu - 1].abs().max()) == 0.0 and float(y[nu + ni - 1].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n,edges", [(1, "none"), (1, "self"), (17, "none"), (17, "multi"), (65, "star"), (200, "range")])
+def test_layer_edge_cases(n, edges):
+    """Graphs at the edges of the schedule: no edges at all, a single node with a self loop, repeated edges
+    (DGL graphs are multigraphs: each copy counts), one row that every node points at, and a cut row whose
+    neighbours all fall in one source range."""
+    rng = np.random.default_rng(n)
+    if edges == "none":
+        src = dst = np.zeros(0, np.int32)
+    elif edges == "self":
+        src = dst = np.zeros(3, np.int32)                       # the same self loop three times
+    elif edges == "multi":
+        src = rng.integers(0, n, 120).astype(np.int32); dst = rng.integers(0, n, 120).astype(np.int32)
+        src, dst = np.concatenate([src, src[:40]]), np.concatenate([dst, dst[:40]])   # 40 duplicated edges
+    elif edges == "star":
+        src = np.concatenate([np.arange(n), np.arange(n), rng.integers(0, n, 100)]).astype(np.int32)
+        dst = np.concatenate([np.zeros(n), np.full(n, 5), rng.integers(0, n, 100)]).astype(np.int32)
+    else:
+        src = np.concatenate([np.tile(np.arange(3, 13), 30), rng.integers(0, n, 300)]).astype(np.int32)   # row 0: 300 edges from 10 sources
+        dst = np.concatenate([np.zeros(300), rng.integers(0, n, 300)]).astype(np.int32)
+    g = dg.CSRGraph(src, dst, n, group_max=4, seg_len=64) if edges in ("star", "range") else dg.CSRGraph(src, dst, n)
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(1))
+    s, d = T(src.astype(np.int64)), T(dst.astype(np.int64))
+    for slope in (0.5, 1.0):
+        assert_rows_close(ops.spmm_norm_act(g, dev(x), slope), O.gcn_layer(s, d, n, x, slope=None if slope == 1.0 else slope),
+                          what=f"{edges} n={n} slope={slope}")
+    assert_rows_close(ops.spmm_norm_act(g, dev(x), 1.0, transpose=True), O.gcn_layer(d, s, n, x, slope=None), what="transpose")
+
+
 def test_layer_module_signatures():
     fx, nu, ni, target, behs = tiny_fixture()
     g = graph_of(fx["target_u"], fx["target_i"], nu, ni)
