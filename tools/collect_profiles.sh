@@ -7,14 +7,17 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 python $R/bench.py --steps 50 --warmup 10 > $O/tmall_bench.json 2> $O/tmall_bench.err
-timeout -k 10 300 python $R/bench.py --workload industry --steps 20 --warmup 5 > $O/industry_bench.json 2> $O/industry_bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_tmall -o p -- python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/ks_tmall.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_industry -o p -- python $R/bench.py --workload industry --steps 20 --warmup 5 --no-cpu-baseline > $O/ks_industry.log 2>&1
+# traffic passes first: the bench lines below read the JSON they produce
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_tmall_$c -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_tmall_$c.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_industry_$c -o p -- python $R/bench.py --workload industry --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_industry_$c.log 2>&1
 done
+python $R/tools/make_traffic_json.py $O/traffic.json tmall $O/pmc_tmall_FETCH_SIZE $O/pmc_tmall_WRITE_SIZE industry $O/pmc_industry_FETCH_SIZE $O/pmc_industry_WRITE_SIZE > /dev/null
+cp $O/traffic.json $R/profiles/${TAG}_traffic.json
+timeout -k 10 300 python $R/bench.py --steps 50 --warmup 10 > $O/tmall_bench.json 2> $O/tmall_bench.err
+timeout -k 10 300 python $R/bench.py --workload industry --steps 20 --warmup 5 > $O/industry_bench.json 2> $O/industry_bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_tmall -o p -- python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/ks_tmall.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_industry -o p -- python $R/bench.py --workload industry --steps 20 --warmup 5 --no-cpu-baseline > $O/ks_industry.log 2>&1
 # SQ / TA / L2 counters of the layer kernel (forward propagation only, tools/layer_bench.py)
 i=0
 : > $O/pmc_gcn_layer.txt
@@ -25,12 +28,11 @@ for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST
   python $R/tools/pmc_summary.py $O/pmc_layer_$i gcn_layer >> $O/pmc_gcn_layer.txt
   python $R/tools/pmc_summary.py $O/pmc_layer_$i hub_reduce >> $O/pmc_gcn_layer.txt
 done
-for w in eval_tmall eval_ijcai negsample_tmall metapath_dblp; do
+for w in eval_tmall eval_ijcai negsample_tmall metapath_dblp predict_ijcai nc_dblp; do
   timeout -k 10 200 python $R/bench.py --workload $w --steps 10 --warmup 3 > $O/${w}_bench.json 2> $O/${w}_bench.err
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_eval -o p -- python $R/bench.py --workload eval_tmall --steps 10 --warmup 3 --no-cpu-baseline > $O/ks_eval.log 2>&1
 cp $O/ks_eval/p_kernel_stats.csv $O/eval_tmall_kernel_stats.csv
-python $R/tools/make_traffic_json.py $O/traffic.json tmall $O/pmc_tmall_FETCH_SIZE $O/pmc_tmall_WRITE_SIZE industry $O/pmc_industry_FETCH_SIZE $O/pmc_industry_WRITE_SIZE > /dev/null
 cp $O/ks_tmall/p_kernel_stats.csv $O/tmall_train_step_kernel_stats.csv
 cp $O/ks_industry/p_kernel_stats.csv $O/industry_1gpu_kernel_stats.csv
 echo done
