@@ -19,6 +19,7 @@ DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE = 1, 2, 4
 DG_BWD_SAVED_PRESCALED = 8
 DG_ACC_REBUILD = 16
 DG_BWD_NORM_FEED = 32
+DG_ROWS_PARTIAL_ONLY, DG_ROWS_FULL_ONLY = 64, 128
 
 
 class DiffGraphHipError(RuntimeError):

@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void gcn_layer_kernel(const dg_task_batch batc
 // Hub rows: one wavefront per row adds the row's slab rows in order, then the epilogue.  Rows of
 // LDS-split tasks have thousands of slab rows (parts x workgroups of window_rows_kernel): there a
 // whole workgroup takes one row, each wavefront a quarter of the slab rows, and wavefront 0 adds
-// the four sums in order.
+// the four sums in order.  (Sixteen wavefronts per row instead of four: no faster -- the rows with
+// the most parts are bound by what one CU can read.)
 __global__ __launch_bounds__(256) void hub_reduce_kernel(const dg_task_batch batch) {
   __shared__ f32x4 red[4][16];
   const dg_task_dev &T = find_task(batch, blockIdx.x, true);
@@ -589,9 +590,24 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   return 0;
 }
 
+constexpr int kExchangeCus = 8;  // CUs kept free of lds_rows_kernel workgroups under DG_ROWS_FULL_ONLY
+
 int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_t stream) {
   const int n_tasks = batch.n_tasks;
   int32_t blocks = 0, hub_blocks = 0;
+  // which rows this call computes (row-sharded runs may ask for the partial-sum rows and the rest separately)
+  constexpr int32_t kRowsMask = DG_ROWS_PARTIAL_ONLY | DG_ROWS_FULL_ONLY;
+  const int32_t rows_sel = batch.t[0].flags & kRowsMask;
+  if (rows_sel == kRowsMask) return dg_fail(DG_ERR_ARG, "layer task: DG_ROWS_PARTIAL_ONLY and DG_ROWS_FULL_ONLY exclude each other");
+  for (int k = 0; k < n_tasks; ++k) {
+    const dg_task_dev &t = batch.t[k];
+    if ((t.flags & kRowsMask) != rows_sel)
+      return dg_fail(DG_ERR_ARG, "layer tasks 0 and %d differ in DG_ROWS_PARTIAL_ONLY / DG_ROWS_FULL_ONLY", k);
+    if (rows_sel && (t.lds_split <= 0 || !t.partial_out || t.partial_from != t.lds_split))
+      return dg_fail(DG_ERR_ARG, "layer task %d: DG_ROWS_*_ONLY needs a graph with one side held in LDS and partial_from at "
+                     "that side's first row (%d), got partial_from %d", k, t.lds_split, t.partial_out ? t.partial_from : -1);
+  }
+  const bool full_rows = rows_sel != DG_ROWS_PARTIAL_ONLY, partial_rows = rows_sel != DG_ROWS_FULL_ONLY;
   for (int k = 0; k < n_tasks; ++k) {
     for (int j = 0; j < k; ++j)
       if (graphs[j] == graphs[k] && batch.t[k].n_seg > 0)
@@ -615,11 +631,14 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     }
     int dev = 0, cus = 256;
     if (wsum > 0 && hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // A call for the non-partial rows alone runs beside the exchange of the partial sums: lds_rows_kernel holds a whole
+    // CU per workgroup until it ends, so a few CUs are left to the collective's kernel.
+    const int lds_cus = rows_sel == DG_ROWS_FULL_ONLY ? std::max(1, cus - kExchangeCus) : cus;
     for (int k = 0; k < n_tasks; ++k) {
       dg_task_dev &t = batch.t[k];
       t.lds_blk_begin = lds_blocks;
       if (w[k] > 0) {
-        int32_t cnt = std::max(1, (int32_t)std::lround(cus * w[k] / wsum));
+        int32_t cnt = std::max(1, (int32_t)(lds_cus * w[k] / wsum));
         cnt = std::min(cnt, (t.lds_split + 63) / 64);
         t.lds_blk_count = cnt;
         lds_blocks += cnt;
@@ -646,7 +665,7 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     }
   }
   for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
-  if (lds_blocks > 0) {
+  if (lds_blocks > 0 && full_rows) {
     const size_t lds_bytes = (size_t)(lds_rows_max + 1) * DG_D * sizeof(float);
     static bool lds_attr_set = false;  // more than 64 KiB of dynamic LDS has to be opted into once
     if (!lds_attr_set) {
@@ -656,7 +675,7 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     }
     hipLaunchKernelGGL(lds_rows_kernel, dim3(lds_blocks), dim3(1024), lds_bytes, stream, batch);
   }
-  if (win_blocks > 0) {
+  if (win_blocks > 0 && partial_rows) {
     constexpr size_t win_lds = (DG_WIN_ROWS + 1) * DG_D * sizeof(float) + DG_WIN_ENT_DWORDS * 4 + 16;
     static bool win_attr_set = false;
     if (!win_attr_set) {
@@ -666,8 +685,9 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     }
     hipLaunchKernelGGL(window_rows_kernel, dim3(win_blocks), dim3(1024), win_lds, stream, batch);
   }
+  // (under DG_ROWS_*_ONLY no task has gcn_layer_kernel rows, and every hub row is a partial-sum row)
   if (blocks > 0) hipLaunchKernelGGL(gcn_layer_kernel, dim3(blocks), dim3(256), 0, stream, batch);
-  if (hub_blocks > 0) hipLaunchKernelGGL(hub_reduce_kernel, dim3(hub_blocks), dim3(256), 0, stream, batch);
+  if (hub_blocks > 0 && partial_rows) hipLaunchKernelGGL(hub_reduce_kernel, dim3(hub_blocks), dim3(256), 0, stream, batch);
   DG_HIP(hipGetLastError());
   return 0;
 }

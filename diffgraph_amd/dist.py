@@ -27,7 +27,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ._lib import DG_ACC_REBUILD, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
+from ._lib import DG_ACC_REBUILD, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE, DG_ROWS_FULL_ONLY, DG_ROWS_PARTIAL_ONLY
 
 
 def user_ranges(n_user: int, world: int) -> List[Tuple[int, int]]:
@@ -68,6 +68,11 @@ class HipBackend:
     def __init__(self, device):
         self.device = device
 
+    def can_split_rows(self, graphs, split: int) -> bool:
+        """Whether layer() accepts DG_ROWS_PARTIAL_ONLY / DG_ROWS_FULL_ONLY for these graphs with the rows from
+        `split` on as the partial-sum rows: every schedule must hold exactly that side in LDS."""
+        return all(g.schedule()["lds_split"] == split for g in graphs)
+
     def make_graph(self, lg: LocalGraph, n_nodes: int):
         from .graph import CSRGraph
         return CSRGraph(lg.src, lg.dst, n_nodes, out_degrees=lg.degrees,
@@ -80,6 +85,19 @@ class HipBackend:
         from . import ops
         ops.gcn_layer_batched([ops.LayerTask(**t) for t in tasks])
 
+    # prepared launches: argument tables built once, for passes repeated over the same buffers
+    def prepare_layer(self, tasks):
+        from . import ops
+        return ops.prepare_gcn_layer_batched([ops.LayerTask(**t) for t in tasks])
+
+    def prepare_finalize(self, tasks):
+        from . import ops
+        return ops.prepare_gcn_partial_finalize_batched([ops.FinalizeTask(**t) for t in tasks])
+
+    def prepare_sum(self, tables, out):
+        from . import ops
+        return ops.prepare_sum_tables(tables, out)
+
     def finalize(self, tasks) -> None:
         from . import ops
         ops.gcn_partial_finalize_batched([ops.FinalizeTask(**t) for t in tasks])
@@ -87,6 +105,35 @@ class HipBackend:
     def sum_tables(self, tables):
         from . import ops
         return ops.sum_tables(tables)
+
+
+class _Pending:
+    """An exchange under way: `wait()` makes the current stream wait for it and returns the gathered tensor."""
+
+    def __init__(self, out: torch.Tensor, work=None):
+        self.out, self.work = out, work
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.out
+
+
+def all_gather_start(t: torch.Tensor, world: int, group=None, out: Optional[torch.Tensor] = None) -> _Pending:
+    """As all_gather_stack (into `out` [world, ...] if given), but on GPU tensors over RCCL the collective is only
+    enqueued (on the communicator's own stream, after everything already enqueued on the current stream): kernels
+    launched before `wait()` run beside it."""
+    import torch.distributed as dist
+    if world > 1 and t.is_cuda and dist.get_backend(group) != "gloo":
+        if out is None:
+            out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        return _Pending(out, dist.all_gather_into_tensor(out, t.contiguous(), group=group, async_op=True))
+    res = all_gather_stack(t, world, group)
+    if out is None:
+        return _Pending(res)
+    out.copy_(res)
+    return _Pending(out)
 
 
 def all_gather_stack(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
@@ -179,7 +226,7 @@ class ShardedRecPropagation:
     """The propagation of HGDM.forward (DiffGraph-Rec/Model.py:53-92) for one rank's user block."""
 
     def __init__(self, interactions: Sequence[Tuple[np.ndarray, np.ndarray]], n_user: int, n_item: int, rank: int,
-                 world: int, backend, n_layers: int = 2, slope: float = 0.5, group=None):
+                 world: int, backend, n_layers: int = 2, slope: float = 0.5, group=None, reuse_buffers: bool = False):
         self.rank, self.world, self.backend, self.group = rank, world, backend, group
         self.n_layers, self.slope = n_layers, slope
         self.u0, self.u1 = user_ranges(n_user, world)[rank]
@@ -189,17 +236,23 @@ class ShardedRecPropagation:
         self.graphs = [backend.make_graph(lg, self.n) for lg in self.local]
         self.edges_global = [lg.n_edges_global for lg in self.local]
         self.hook = None
+        # two launches per layer (item partial sums, then the user rows beside the exchange) where the kernels allow
+        self.split_rows = world > 1 and backend.can_split_rows(self.graphs, self.n_loc)
+        self.reuse_buffers = reuse_buffers
+        self._programs = {}
 
-    def _exchange(self, partials: torch.Tensor) -> torch.Tensor:
-        """[G, n_item, 64] on every rank -> [world, G, n_item, 64] (partial sums in rank order)."""
-        return all_gather_stack(partials, self.world, self.group)
+    def _exchange(self, partials: torch.Tensor, out: torch.Tensor) -> _Pending:
+        """[G, n_item, 64] on every rank -> out [world, G, n_item, 64] (partial sums in rank order), valid after
+        `.wait()`."""
+        return all_gather_start(partials, self.world, self.group, out)
 
-    def forward(self, e0: torch.Tensor):
-        """e0: [n_loc + n_item, 64] = this rank's user rows, then the (replicated) item rows.
-        Returns (ui, het) in the same layout; item rows are identical on every rank."""
+    def _program(self, e0: torch.Tensor):
+        """Allocates the buffers of a forward pass over `e0` and prepares its launches.
+        Returns (steps, (ui, het)): calling the steps in order fills the two output tables."""
         be, G, L = self.backend, len(self.graphs), self.n_layers
         sums = [be.empty(self.n) for _ in range(G)]
         prev: List[Optional[torch.Tensor]] = [None] * G
+        steps, tail = [], []       # tail: the previous layer's wait + finalize, still to be placed
         for l in range(L):
             last = l == L - 1
             flags = (DG_IN_PRESCALED if l > 0 else 0) | (0 if last else DG_OUT_PRESCALE)
@@ -207,6 +260,7 @@ class ShardedRecPropagation:
             if l == 1:
                 flags |= DG_ACC_REBUILD
             partials = torch.empty((G, self.n_item, DG_D), dtype=torch.float32, device=e0.device)
+            gathered = torch.empty((self.world,) + tuple(partials.shape), dtype=torch.float32, device=e0.device)
             outs, tasks = [], []
             for g in range(G):
                 e_out = None if last else be.empty(self.n)
@@ -215,17 +269,55 @@ class ShardedRecPropagation:
                 tasks.append(dict(graph=self.graphs[g], x=e0 if l == 0 else prev[g], e_out=e_out,
                                   acc_in=acc_in, acc_out=None if skip_sum else sums[g], flags=flags, slope=self.slope,
                                   partial_out=partials[g], partial_from=self.n_loc))
-            if self.hook:
-                self.hook("begin", l)
-            be.layer(tasks)
-            gathered = self._exchange(partials)
-            be.finalize([dict(graph=self.graphs[g], partials=gathered[:, g], row_begin=self.n_loc, e_out=outs[g],
-                              acc_in=tasks[g]["acc_in"], acc_out=tasks[g]["acc_out"], flags=flags, slope=self.slope,
-                              x=tasks[g]["x"]) for g in range(G)])
-            if self.hook:
-                self.hook("end", l)
+            pending: List[Optional[_Pending]] = [None]
+
+            def start(p=partials, o=gathered, slot=pending):
+                slot[0] = self._exchange(p, o)
+
+            def wait(slot=pending):
+                slot[0].wait()
+                slot[0] = None
+            fin = be.prepare_finalize(
+                [dict(graph=self.graphs[g], partials=gathered[:, g], row_begin=self.n_loc, e_out=outs[g],
+                      acc_in=tasks[g]["acc_in"], acc_out=tasks[g]["acc_out"], flags=flags, slope=self.slope,
+                      x=tasks[g]["x"]) for g in range(G)])
+            if self.split_rows:
+                # Two launches: the item partial sums, then the user rows.  The first needs only the user rows of the
+                # previous layer, so it goes ahead of that layer's wait + finalize: an exchange runs beside the user
+                # rows of its own layer and the partial sums of the next.
+                steps += [be.prepare_layer([dict(t, flags=t["flags"] | DG_ROWS_PARTIAL_ONLY) for t in tasks]), start]
+                steps += tail
+                steps.append(be.prepare_layer([dict(t, flags=t["flags"] | DG_ROWS_FULL_ONLY) for t in tasks]))
+            else:
+                steps += tail + [be.prepare_layer(tasks), start]
+            tail = [wait, fin]
             prev = outs
-        return sums[0], be.sum_tables(sums[1:])
+        steps += tail
+        if G > 2:
+            het = be.empty(self.n)
+            steps.append(be.prepare_sum(sums[1:], het))
+        else:
+            het = sums[1] if G == 2 else None
+        return steps, (sums[0], het)
+
+    def forward(self, e0: torch.Tensor):
+        """e0: [n_loc + n_item, 64] = this rank's user rows, then the (replicated) item rows.
+        Returns (ui, het) in the same layout; item rows are identical on every rank.  With `reuse_buffers` the
+        buffers and prepared launches of the first call over a table are kept: the returned tables are then
+        overwritten by the next call over the same table."""
+        key = (e0.data_ptr(), tuple(e0.shape), str(e0.device))
+        prog = self._programs.get(key) if self.reuse_buffers else None
+        if prog is None:
+            prog = self._program(e0)
+            if self.reuse_buffers:
+                self._programs = {key: prog + (e0,)}    # one table at a time; e0 is kept so its address stays taken
+        if self.hook:
+            self.hook("begin")
+        for step in prog[0]:
+            step()
+        if self.hook:
+            self.hook("end")
+        return prog[1]
 
 
 # --------------------------------------------------------------------------------------
@@ -247,14 +339,14 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
             p = RowBlockPropagation(edges, wl.n, rk, wd, HipBackend(device))
             full = torch.cat([torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)), ie])
             return p, full[p.r0:p.r1].to(device)
-        p = ShardedRecPropagation(inter, wl.n_user, wl.n_item, rk, wd, HipBackend(device))
+        p = ShardedRecPropagation(inter, wl.n_user, wl.n_item, rk, wd, HipBackend(device), reuse_buffers=True)
         ue = torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)[p.u0:p.u1])
         return p, torch.cat([ue, ie]).to(device)
     prop, e0 = make(rank, world)
 
     events = []
 
-    def hook(phase, layer):
+    def hook(phase, layer=None):
         if hook.enabled:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream())
@@ -286,9 +378,11 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
         prop.forward(e0)
     torch.cuda.synchronize()
     hook.enabled = False
-    layer_ms = float(np.mean([events[k].elapsed_time(events[k + 1]) for k in range(0, len(events), 2)]))
-
     L = prop.n_layers
+    # row blocks: one event pair per layer; user-row shards: one pair per forward pass (its layers interleave)
+    layer_ms = float(np.mean([events[k].elapsed_time(events[k + 1]) for k in range(0, len(events), 2)]))
+    if not row_blocks:
+        layer_ms /= L
     nnz = prop.edges_global
     n_total = wl.n
     layer_bytes_global = sum(4 * e + 1032 * n_total for e in nnz)
@@ -328,7 +422,7 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
                        "parallelism": f"row blocks x{world}" if row_blocks else f"user-row shards x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": "one sharded propagation layer on rank 0 (propagation kernels + "
-                         "exchange + partial_finalize_kernel)",
+                         "exchange + partial_finalize_kernel; user-row shards: a forward pass / its layers)",
                          "bytes_per_launch": per_rank_bytes, "ms_per_launch": layer_ms},
         }
         if single is not None:

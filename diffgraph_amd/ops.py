@@ -78,8 +78,13 @@ def _row_vector(v: torch.Tensor, name: str, n: int) -> None:
 
 def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
     """One fused propagation layer (SpMM + LeakyReLU + normalise + layer sum) over several graphs."""
-    if not tasks:
-        return
+    if tasks:
+        prepare_gcn_layer_batched(tasks)()
+
+
+def prepare_gcn_layer_batched(tasks: Sequence[LayerTask]):
+    """Checks the tasks and builds the call's argument table once; returns a function that launches the layer on the
+    current stream.  For loops that run the same launch over the same buffers many times."""
     n_tasks = len(tasks)
     if n_tasks > _lib.DG_MAX_TASKS:
         raise DiffGraphHipError(f"at most {_lib.DG_MAX_TASKS} graphs per batched layer launch")
@@ -99,8 +104,11 @@ def gcn_layer_batched(tasks: Sequence[LayerTask]) -> None:
         arr[k] = _lib.LayerTask(t.graph.handle, t.x.data_ptr(), _ptr(t.e_out), _ptr(t.acc_in), _ptr(t.acc_out),
                                 int(t.flags), float(t.slope), _ptr(t.partial_out), int(t.partial_from),
                                 _ptr(t.row_norm_out))
-    rc = _lib.load().dg_gcn_layer_fwd(arr, n_tasks, DG_D, _lib.stream_ptr(dev))
-    _lib.check(rc, "dg_gcn_layer_fwd")
+    fn, keep = _lib.load().dg_gcn_layer_fwd, list(tasks)   # the table holds raw pointers: keep the tensors alive
+
+    def launch(_keep=keep):
+        _lib.check(fn(arr, n_tasks, DG_D, _lib.stream_ptr(dev)), "dg_gcn_layer_fwd")
+    return launch
 
 
 @dataclass
@@ -118,8 +126,12 @@ class FinalizeTask:
 
 def gcn_partial_finalize_batched(tasks: Sequence[FinalizeTask]) -> None:
     """Second half of a row-sharded layer for all its graphs in one launch (see dg_gcn_partial_finalize)."""
-    if not tasks:
-        return
+    if tasks:
+        prepare_gcn_partial_finalize_batched(tasks)()
+
+
+def prepare_gcn_partial_finalize_batched(tasks: Sequence[FinalizeTask]):
+    """As prepare_gcn_layer_batched, for the second half of a row-sharded layer."""
     n_tasks = len(tasks)
     if n_tasks > _lib.DG_MAX_TASKS:
         raise DiffGraphHipError(f"at most {_lib.DG_MAX_TASKS} graphs per batched launch")
@@ -136,8 +148,11 @@ def gcn_partial_finalize_batched(tasks: Sequence[FinalizeTask]) -> None:
         arr[k] = _lib.FinalizeTask(t.graph.handle, p.data_ptr(), p.shape[0], p.stride(0) // DG_D, int(t.row_begin),
                                    p.shape[1], _ptr(t.x), _ptr(t.e_out), _ptr(t.acc_in), _ptr(t.acc_out), int(t.flags),
                                    float(t.slope))
-    rc = _lib.load().dg_gcn_partial_finalize_batched(arr, n_tasks, DG_D, _lib.stream_ptr(tasks[0].partials.device))
-    _lib.check(rc, "dg_gcn_partial_finalize_batched")
+    fn, keep, dev = _lib.load().dg_gcn_partial_finalize_batched, list(tasks), tasks[0].partials.device
+
+    def launch(_keep=keep):
+        _lib.check(fn(arr, n_tasks, DG_D, _lib.stream_ptr(dev)), "dg_gcn_partial_finalize_batched")
+    return launch
 
 
 def gcn_partial_finalize(graph: CSRGraph, partials: torch.Tensor, row_begin: int, e_out, acc_in, acc_out, flags: int,
@@ -185,13 +200,21 @@ def sum_tables(tables: Sequence[torch.Tensor]) -> torch.Tensor:
     """((t0 + t1) + t2) + ... like Python's sum(list) (Model.py:87)."""
     if len(tables) == 1:
         return tables[0]
-    for t in tables:
-        _table(t, "table", tables[0].shape[0])
     out = torch.empty_like(tables[0])
-    ptrs = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
-    rc = _lib.load().dg_sum_tables(ptrs, len(tables), out.data_ptr(), out.numel(), _lib.stream_ptr(out.device))
-    _lib.check(rc, "dg_sum_tables")
+    prepare_sum_tables(tables, out)()
     return out
+
+
+def prepare_sum_tables(tables: Sequence[torch.Tensor], out: torch.Tensor):
+    """Returns a function that writes ((t0 + t1) + ...) into `out` on the current stream."""
+    for t in list(tables) + [out]:
+        _table(t, "table", tables[0].shape[0])
+    ptrs = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
+    fn, keep, n_in = _lib.load().dg_sum_tables, list(tables) + [out], len(tables)
+
+    def launch(_keep=keep):
+        _lib.check(fn(ptrs, n_in, out.data_ptr(), out.numel(), _lib.stream_ptr(out.device)), "dg_sum_tables")
+    return launch
 
 
 # --------------------------------------------------------------------------------------

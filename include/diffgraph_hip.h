@@ -102,6 +102,13 @@ enum { DG_IN_PRESCALED = 1, DG_OUT_NORM = 2, DG_OUT_PRESCALE = 4, DG_ACC_REBUILD
  * running sum; acc_in points at the layer-0 table e0 and the sum so far is rebuilt per row as
  * e0[i] + normalize(x[i])  (x[i] = dinv_src[i] * E_1[i], so normalize(x[i]) is the first
  * layer's normalised activation).  Saves one table write and one cold table read per graph. */
+enum { DG_ROWS_PARTIAL_ONLY = 64, DG_ROWS_FULL_ONLY = 128 };
+/* Row-sharded runs may cut a layer call in two so that the exchange of the partial sums overlaps
+ * the rest of the layer: a call with DG_ROWS_PARTIAL_ONLY computes only the rows >= partial_from
+ * (their partial sums), a call with DG_ROWS_FULL_ONLY only the rows below; the two together equal
+ * one call with neither flag.  All tasks of a call carry the same choice.  Accepted for graphs
+ * whose schedule keeps the two row classes in separate launches (one small side held in LDS, with
+ * partial_from equal to the first row of that side); an argument error otherwise. */
 
 typedef struct dg_layer_task {
   dg_graph *graph;

@@ -6,10 +6,14 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
-from diffgraph_amd._lib import DG_ACC_REBUILD, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE
+from diffgraph_amd._lib import (DG_ACC_REBUILD, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE, DG_ROWS_FULL_ONLY,
+                                DG_ROWS_PARTIAL_ONLY)
 
 
 class CpuBackend:
+    def can_split_rows(self, graphs, split):
+        return True
+
     def make_graph(self, lg, n_nodes):
         deg = torch.from_numpy(lg.degrees).float().clamp(min=1)
         owned = None
@@ -40,10 +44,21 @@ class CpuBackend:
             h = x[: g.n] if t["flags"] & DG_IN_PRESCALED else x[: g.n] * g.dinv
             s = torch.zeros_like(h).index_add_(0, g.dst, h[g.src])
             pf = t["partial_from"] if t.get("partial_out") is not None else g.n
-            if t.get("partial_out") is not None:
+            if t.get("partial_out") is not None and not t["flags"] & DG_ROWS_FULL_ONLY:
                 t["partial_out"].copy_(s[pf:])
+            if t["flags"] & DG_ROWS_PARTIAL_ONLY:
+                continue
             rows = slice(0, pf) if g.owned is None else g.owned
             self._epilogue(g, rows, s[rows], t["e_out"], t["acc_in"], t["acc_out"], t["flags"], t["slope"], x)
+
+    def prepare_layer(self, tasks):
+        return lambda: self.layer(tasks)
+
+    def prepare_finalize(self, tasks):
+        return lambda: self.finalize(tasks)
+
+    def prepare_sum(self, tables, out):
+        return lambda: out.copy_(self.sum_tables(tables))
 
     def finalize(self, tasks):
         for t in tasks:

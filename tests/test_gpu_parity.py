@@ -597,7 +597,7 @@ def test_nc_cal_loss_gradients_golden():
 def _run_sharded_threads(inter, n_user, n_item, e_user, e_item, world):
     """`world` user shards on ONE GPU, one thread per emulated rank, lock-step fake all-gather."""
     import threading
-    from diffgraph_amd.dist import HipBackend, ShardedRecPropagation
+    from diffgraph_amd.dist import HipBackend, ShardedRecPropagation, _Pending
     barrier = threading.Barrier(world)
     shared = [None] * world
     results = [None] * world
@@ -608,13 +608,13 @@ def _run_sharded_threads(inter, n_user, n_item, e_user, e_item, world):
             torch.cuda.set_device(0)
             prop = ShardedRecPropagation(inter, n_user, n_item, rank, world, HipBackend(torch.device(DEV)))
 
-            def exchange(partials):
+            def exchange(partials, out):
                 shared[rank] = partials
                 barrier.wait()
-                out = torch.stack(list(shared), dim=0)
+                torch.stack(list(shared), dim=0, out=out)
                 torch.cuda.synchronize()
                 barrier.wait()
-                return out
+                return _Pending(out)
             prop._exchange = exchange
             e0 = torch.cat([e_user[prop.u0:prop.u1], e_item]).to(DEV)
             ui, het = prop.forward(e0)
@@ -742,3 +742,40 @@ def test_lds_resident_small_side_matches_oracle():
     tu, ti, hu, hi = O.rec_forward(edges_t(*inter[0], nu), [edges_t(*b, nu) for b in inter[1:]], ue_, ie_, 2)
     ((torch.cat([tu, ti]) * r1).sum() + (torch.cat([hu, hi]) * r2).sum()).backward()
     assert_rows_close(m.embedding_table.grad, torch.cat([ue_.grad, ie_.grad]), rtol=2e-5, what="lds path d e0")
+
+
+def test_sharded_lds_graphs_split_layer_calls():
+    """Industry-shaped shards: each layer runs as two calls (item partial sums, then the user rows) so that the
+    exchange can overlap the second; the result equals the one-call path's and the oracle's."""
+    from diffgraph_amd.dist import HipBackend, ShardedRecPropagation
+    nu, ni, world = 9000, 37, 3
+    inter = [dgdata.synth_interactions(nu, ni, m, seed) for m, seed in ((30000, 1), (80000, 2), (12000, 3))]
+    ue, ie = T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))
+    probe = ShardedRecPropagation(inter, nu, ni, 1, world, HipBackend(torch.device(DEV)))
+    assert probe.split_rows
+    res = _run_sharded_threads(inter, nu, ni, ue, ie, world)
+    tu, ti, hu, hi = O.rec_forward(edges_t(*inter[0], nu), [edges_t(*b, nu) for b in inter[1:]], ue, ie, 2)
+    assert_rows_close(torch.cat([r[2][: r[1] - r[0]] for r in res]), tu, what="split calls: target users")
+    assert_rows_close(torch.cat([r[3][: r[1] - r[0]] for r in res]), hu, what="split calls: heter users")
+    for r in res:
+        assert_rows_close(r[2][r[1] - r[0]:], ti, what="split calls: target items")
+        assert_rows_close(r[3][r[1] - r[0]:], hi, what="split calls: heter items")
+    # the two calls against one call, same shard: bit-identical
+    e0 = torch.cat([ue[probe.u0:probe.u1], ie]).to(DEV)
+    from diffgraph_amd.dist import _Pending
+    probe._exchange = lambda p, out: _Pending(torch.stack([p, p, p], out=out))
+    a = [t.clone() for t in probe.forward(e0)]
+    probe.split_rows = False
+    b = probe.forward(e0)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_row_selection_flags_rejected_for_general_schedules():
+    from diffgraph_amd._lib import DG_ROWS_PARTIAL_ONLY, DiffGraphHipError
+    fx, nu, ni, target, behs = tiny_fixture()
+    g = graph_of(fx["target_u"], fx["target_i"], nu, ni)
+    x = dev(torch.randn(nu + ni, 64))
+    part = torch.empty(ni, 64, device=DEV)
+    with pytest.raises(DiffGraphHipError):
+        ops.gcn_layer_batched([ops.LayerTask(graph=g, x=x, e_out=torch.empty_like(x), acc_in=None, acc_out=None,
+                                             flags=DG_ROWS_PARTIAL_ONLY, slope=0.5, partial_out=part, partial_from=nu)])
