@@ -779,3 +779,56 @@ def test_row_selection_flags_rejected_for_general_schedules():
     with pytest.raises(DiffGraphHipError):
         ops.gcn_layer_batched([ops.LayerTask(graph=g, x=x, e_out=torch.empty_like(x), acc_in=None, acc_out=None,
                                              flags=DG_ROWS_PARTIAL_ONLY, slope=0.5, partial_out=part, partial_from=nu)])
+
+
+def _oracle_weights(dn) -> O.DenoiseWeights:
+    c = lambda t: t.detach().cpu().clone()
+    return O.DenoiseWeights(c(dn.emb_layer.weight), c(dn.emb_layer.bias), c(dn.in_layers[0].weight), c(dn.in_layers[0].bias),
+                            c(dn.out_layers[0].weight), c(dn.out_layers[0].bias))
+
+
+def test_ijcai_size_predict_against_oracle():
+    """The IJCAI-shaped configuration at full size: HGDM.predict (propagation + the 200-step reverse loop for users and
+    items) against the oracle -- the whole propagation, and the loop on sampled rows (it is row-independent)."""
+    wl = dgdata.rec_workload("ijcai")
+    nu, ni = wl.n_user, wl.n_item
+    graphs = [graph_of(*ui, nu, ni) for ui in [wl.target] + wl.behaviours]
+    from types import SimpleNamespace
+    torch.manual_seed(11)
+    m = dg.rec.HGDM(SimpleNamespace(userNum=nu, itemNum=ni, target_adj=graphs[0], behavior_mats=graphs[1:])).eval()
+    ue, ie = T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))
+    m.set_embeddings(dev(ue), dev(ie))
+    with torch.no_grad():
+        pu, pi = m.predict()
+        fwd = m.forward()
+    tu, ti, hu, hi = O.rec_forward(edges_t(*wl.target, nu), [edges_t(*b, nu) for b in wl.behaviours], ue, ie, 2)
+    for got, want, nm in zip(fwd, (tu, ti, hu, hi), ("tu", "ti", "hu", "hi")):
+        assert_rows_close(got, want, what="ijcai forward " + nm)
+    tab = O.DiffusionTables(**REC_TABLE)
+    gen = torch.Generator().manual_seed(3)
+    for got, base, h, dn, nm in ((pu, tu, hu, m.usr_denoiser, "users"), (pi, ti, hi, m.item_denoiser, "items")):
+        rows = torch.randperm(h.shape[0], generator=gen)[:96]
+        want = base[rows] + O.p_sample(tab, _oracle_weights(dn), h[rows], 0)
+        assert_rows_close(got[rows.to(DEV)], want, rtol=2e-5, what="ijcai predict " + nm)
+    assert torch.isfinite(pu).all() and torch.isfinite(pi).all()
+
+
+def test_industry_size_forward_against_oracle():
+    """The Industry-shaped graph at full size (1M x 361, 47.8M directed edges): the whole two-layer forward, every
+    row, against the oracle evaluated in fp64.  (Item rows here sum 10^4..10^6 neighbours: the fp32 oracle adds
+    them one after the other and is itself 1.5e-5 off in a few entries; the kernels add fixed-order partial sums.)"""
+    wl = dgdata.rec_workload("industry")
+    nu, ni = wl.n_user, wl.n_item
+    graphs = [graph_of(*ui, nu, ni) for ui in [wl.target] + wl.behaviours]
+    assert all(g.schedule()["lds_split"] == nu for g in graphs)
+    from types import SimpleNamespace
+    m = dg.rec.HGDM(SimpleNamespace(userNum=nu, itemNum=ni, target_adj=graphs[0], behavior_mats=graphs[1:])).eval()
+    ue, ie = T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))
+    m.set_embeddings(dev(ue), dev(ie))
+    with torch.no_grad():
+        fwd = [t.cpu() for t in m.forward()]
+    del m, graphs
+    want = O.rec_forward(edges_t(*wl.target, nu), [edges_t(*b, nu) for b in wl.behaviours], ue.double(), ie.double(), 2)
+    for got, w, nm in zip(fwd, want, ("tu", "ti", "hu", "hi")):
+        assert w.dtype == torch.float64
+        assert_rows_close(got, w, what="industry forward " + nm)
