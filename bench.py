@@ -144,11 +144,13 @@ def main():
         return
 
     workload = args.workload or "tmall"
-    if workload.startswith(("eval_", "negsample_", "metapath", "predict_", "nc_dblp")):
+    if workload.startswith(("eval_", "negsample_", "metapath", "predict_", "nc_dblp", "epoch_")):
         # the stages either side of the propagation path (evaluation, sampling, graph construction)
         from diffgraph_amd import bench_next
         if workload.startswith("eval_"):
             res = bench_next.bench_eval(workload[5:], args.steps, args.warmup, not args.no_cpu_baseline)
+        elif workload.startswith("epoch_"):
+            res = bench_next.bench_epoch(workload[6:], args.steps, args.warmup, not args.no_cpu_baseline)
         elif workload.startswith("predict_"):
             res = bench_next.bench_predict(workload[8:], args.steps, args.warmup, not args.no_cpu_baseline)
         elif workload.startswith("nc_dblp"):
@@ -161,15 +163,17 @@ def main():
         return
     wl, graphs, model = build_rec(workload, device)
     n = wl.n
-    gen = torch.Generator().manual_seed(1)
     B = model.args.batch
-    ancs = torch.randint(0, wl.n_user, (B,), generator=gen).to(device)
-    poss = torch.randint(0, wl.n_item, (B,), generator=gen).to(device)
-    negs = torch.randint(0, wl.n_item, (B,), generator=gen).to(device)
-    ts_u = torch.randint(0, 200, (wl.n_user,), generator=gen).to(device)
-    ts_i = torch.randint(0, 200, (wl.n_item,), generator=gen).to(device)
-    noise_u = torch.randn(wl.n_user, 64, generator=torch.Generator().manual_seed(2)).to(device)
-    noise_i = torch.randn(wl.n_item, 64, generator=torch.Generator().manual_seed(22)).to(device)
+    # a real batch: shuffled pairs of the target behaviour with one sampled negative each, as trainEpoch feeds them
+    # (popular items are named by many entries of a batch; uniform random indices would hide that)
+    import scipy.sparse as sp
+    from diffgraph_amd.sampling import PairwiseTrnData
+    tu, ti = wl.target
+    trn = PairwiseTrnData(sp.coo_matrix((np.ones(len(tu), np.float32), (tu, ti)), shape=(wl.n_user, wl.n_item)), device=device, seed=1)
+    trn.negSampling()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1)
+    ancs, poss, negs = next(trn.batches(B, shuffle=True, generator=gen))
 
     timer = LayerTimer()
     model.layer_hook = timer

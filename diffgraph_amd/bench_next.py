@@ -263,3 +263,97 @@ def bench_nc_dblp(steps: int, warmup: int, cpu_baseline: bool):
         res["cpu_baseline"] = {"value": k * L * sum(nnz) / el, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"{k} x the forward (projection + {L} layers x 3 graphs, index_add_ form), {el:.1f} s"}
     return res
+
+
+def bench_epoch(workload: str, steps: int, warmup: int, cpu_baseline: bool):
+    """One step = one EPOCH of Coach (DiffGraph-Rec/main.py:78-94): trainEpoch -- negative sampling, every shuffled
+    batch of the target behaviour through cal_loss + backward + Adam -- then testEpoch (predict with the 200-step
+    reverse loop, all-rank top-20, Recall / NDCG), as the reference tests after every epoch."""
+    import diffgraph_amd as dg
+    from types import SimpleNamespace
+    from .train import Coach
+    wl = dgdata.rec_workload(workload)
+    nu, ni = wl.n_user, wl.n_item
+    graphs = [dg.CSRGraph.from_bipartite(u, i, nu, ni) for (u, i) in [wl.target] + wl.behaviours]
+    rng = np.random.default_rng(11)
+    tst_u, tst_i = np.arange(nu, dtype=np.int32), rng.integers(0, ni, nu).astype(np.int32)
+    trn = _coo(*wl.target, nu, ni)
+    handler = SimpleNamespace(userNum=nu, itemNum=ni, target_adj=graphs[0], behavior_mats=graphs[1:],
+                              trn_data=PairwiseTrnData(trn, seed=1), tst_data=ev.AllRankTestData(_coo(tst_u, tst_i, nu, ni), trn))
+    torch.manual_seed(3)
+    coach = Coach(handler, seed=5)
+    coach.prepareModel()
+    model, B = coach.model, coach.args.batch
+    times = {"train": 0.0, "test": 0.0}
+    last = {}
+
+    def epoch(timed: bool):
+        t0 = time.perf_counter()
+        last["train"] = coach.trainEpoch()            # ends with the epoch's one read-back of the loss sums
+        t1 = time.perf_counter()
+        last["test"] = coach.testEpoch()              # ends with the metrics on the host
+        t2 = time.perf_counter()
+        if timed:
+            times["train"] += t1 - t0
+            times["test"] += t2 - t1
+    for _ in range(max(warmup, 1)):                   # the first epoch records the step's HIP graph
+        epoch(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        epoch(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    # the propagation layer's launch time for the roofline: HIP events round each fused layer launch, back to back
+    pairs = []
+
+    def hook(phase, layer):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        pairs.append(e)
+    with torch.no_grad():
+        for _ in range(5):
+            model.propagate(model.embedding_table)
+        torch.cuda.synchronize()
+        model.layer_hook = hook
+        for _ in range(20):
+            model.propagate(model.embedding_table)
+        torch.cuda.synchronize()
+        model.layer_hook = None
+    layer_ms = float(np.mean([pairs[k].elapsed_time(pairs[k + 1]) for k in range(0, len(pairs), 2)]))
+    L, n = model.n_layers, wl.n
+    nnz = [g.num_edges() for g in graphs]
+    n_pairs = len(handler.trn_data)
+    n_batches = -(-n_pairs // B)
+    edges_per_epoch = (2 * L * n_batches + L) * sum(nnz)      # forward + backward per batch, one forward in predict
+    layer_bytes = sum(4 * e + 1032 * n for e in nnz)
+    achieved = layer_bytes / (layer_ms * 1e-3) / 1e9
+    res = {"metric": "SpMM edges/sec + achieved HBM GB/s per propagation layer", "value": edges_per_epoch * steps / elapsed,
+           "unit": "edges/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"epoch_{workload}: {wl.note}; one step = one full epoch (trainEpoch + testEpoch)",
+                      "n_user": nu, "n_item": ni, "graphs": len(graphs), "directed_edges_per_graph": nnz, "layers": L,
+                      "train_pairs": n_pairs, "batch": B, "batches_per_epoch": n_batches,
+                      "train_ms_per_epoch": times["train"] / steps * 1e3, "test_ms_per_epoch": times["test"] / steps * 1e3,
+                      "last_epoch": {**last["train"], **last["test"]},
+                      "launch": "hip-graph replay (one recording per batch size: full and last)"},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "gcn_layer_kernel + hub_reduce_kernel (one fused propagation layer, all graphs)",
+                        "bytes_per_launch": layer_bytes, "ms_per_launch": layer_ms}}
+    if cpu_baseline:
+        from oracle import ref_cpu as O
+        T = torch.from_numpy
+        ue, ie = T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))
+        mk = lambda ui: tuple(T(a.astype(np.int64)) for a in dgdata.bipartite_edges(ui[0], ui[1], nu))
+        target, behs = mk(wl.target), [mk(b) for b in wl.behaviours]
+        O.rec_forward(target, behs, ue, ie, L)
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 10.0:
+            O.rec_forward(target, behs, ue, ie, L)
+            k += 1
+        el = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": k * L * sum(nnz) / el, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{k} forward propagation passes of the {workload} workload (index_add_ form), torch CPU, "
+                                         f"{el:.1f} s; an epoch of the reference adds the backward pass, {n_batches} times"}
+    return res

@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kSlots = 6;       // entries of one table row remembered per row; rows named more often are scanned for
+constexpr int kSlots = 6;       // entries of one table row remembered per row; rows named more often go to head_heavy_kernel
 constexpr int kMaxBatch = 8192;  // the three index lists of a batch sit in LDS as int32: 96 KiB at most
 
 template <int CTRL>
@@ -135,37 +135,28 @@ __global__ __launch_bounds__(256) void head_bwd_entries_kernel(const float *ui, 
 
 // Entry e of the user list or of the item list writes its row of the gradient tables when it is
 // the only entry naming that row; when several do, the first of them adds the later ones in list
-// order and the others leave.  A workgroup with such a first entry copies the lists into LDS once
-// (as int32) and the entry's group scans its list there, 16 entries per step.
-__global__ __launch_bounds__(256) void head_scatter_kernel(const int64_t *ancs, const int64_t *poss, const int64_t *negs,
-                                                           int n_batch, int n_user, const double *g, const float *scratch,
-                                                           const int *tag, const int *cnt, const int *slots, float *d_ui,
-                                                           float *d_out_u, float *d_out_i, double *d_rl_u, double *d_rl_i) {
-  extern __shared__ int idx[];  // [3 * n_batch]: ancs | poss | negs
-  const int e_all = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15, q = (threadIdx.x & 63) >> 4;
-  const bool valid = e_all < 3 * n_batch;
+// order (from the row's slots) and the others leave.  Rows named more often than there are slots
+// -- popular items turn up a hundred times in a batch of real interactions -- are handed to
+// head_heavy_kernel through a list (its order does not matter: a row is summed by one workgroup).
+__global__ __launch_bounds__(256) void head_scatter_kernel(int n_batch, int n_user, const double *g, const float *scratch,
+                                                           const int *tag, const int *cnt, const int *slots, int *heavy,
+                                                           float *d_ui, float *d_out_u, float *d_out_i, double *d_rl_u,
+                                                           double *d_rl_i) {
+  const int e_all = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  if (e_all >= 3 * n_batch) return;
   const bool user = e_all < n_batch;
   const int e = user ? e_all : e_all - n_batch, m = user ? n_batch : 2 * n_batch;
   const int *idx32 = reinterpret_cast<const int *>(scratch + (size_t)3 * n_batch * DG_D);  // ancs | poss | negs as int32
-  int row = 0, trow = 0, c = 0;
-  bool owner = false;
-  if (valid) {
-    row = idx32[e_all];
-    trow = user ? row : n_user + row;
-    c = cnt[trow];
-    owner = c == 1 || m - tag[trow] == e;  // the only entry naming this row, or the first of several
+  const int row = idx32[e_all], trow = user ? row : n_user + row, c = cnt[trow];
+  if (c != 1 && m - tag[trow] != e) return;  // not the only entry naming this row, nor the first of several
+  if (c > kSlots) {
+    if (l == 0) heavy[1 + atomicAdd(heavy, 1)] = e_all;
+    return;
   }
-  const bool scan = owner && c > kSlots;  // more entries than slots: look for them in the list itself
-  if (__syncthreads_or(scan)) {
-#pragma unroll 4
-    for (int i = threadIdx.x; i < 3 * n_batch; i += 256) idx[i] = idx32[i];
-    __syncthreads();
-  }
-  if (!owner) return;  // (whole groups leave)
   const f32x4 *G = reinterpret_cast<const f32x4 *>(scratch) + (user ? (size_t)0 : (size_t)n_batch * 16);
   f32x4 acc = G[(size_t)e * 16 + l];
   int n_loss = user || e < n_batch ? 1 : 0;  // entries that carry a diffusion-loss row: ancs, poss
-  if (c > 1 && !scan) {
+  if (c > 1) {
     // the row's entries from its slots, put in ascending order (they were stored in arrival order)
     int s[kSlots];
 #pragma unroll
@@ -183,30 +174,67 @@ __global__ __launch_bounds__(256) void head_scatter_kernel(const int64_t *ancs, 
         acc += G[(size_t)s[k] * 16 + l];
         n_loss += (user || s[k] < n_batch) ? 1 : 0;
       }
-  } else if (scan) {
+  }
+  reinterpret_cast<f32x4 *>(d_ui)[(size_t)trow * 16 + l] = acc;
+  reinterpret_cast<f32x4 *>(user ? d_out_u : d_out_i)[(size_t)row * 16 + l] = acc;
+  if (l == 0) (user ? d_rl_u : d_rl_i)[row] = (g[0] + g[3]) * n_loss / n_batch;
+}
+
+// Rows with more entries than slots, one 1024-thread workgroup per row at a time.  The row's list (the users' or
+// the items', as int32 in LDS) is cut into 64 equal runs from the row's first entry on; each 16-lane group looks
+// through one run, 16 entries per step, and adds the gradients of the entries naming the row in list order; the 64
+// sums are then added in run order.  Fixed runs, fixed order: the result does not depend on timing.  (The adds of a
+// run wait for their loads one after the other, so a row named 200 times wants many short runs.)
+constexpr int kHeavyBlocks = 128, kHeavyRuns = 64;
+__global__ __launch_bounds__(16 * kHeavyRuns) void head_heavy_kernel(int n_batch, int n_user, const double *g,
+                                                                     const float *scratch, const int *heavy, float *d_ui,
+                                                                     float *d_out_u, float *d_out_i, double *d_rl_u,
+                                                                     double *d_rl_i) {
+  extern __shared__ int idx[];  // [3 * n_batch]: ancs | poss | negs
+  __shared__ f32x4 red[kHeavyRuns][16];
+  __shared__ int red_n[kHeavyRuns];
+  const int n_heavy = min(heavy[0], n_batch);  // (at most 3 n_batch / 7 rows can be named seven times)
+  if ((int)blockIdx.x >= n_heavy) return;      // (the whole workgroup)
+  const int *idx32 = reinterpret_cast<const int *>(scratch + (size_t)3 * n_batch * DG_D);
+  for (int i = threadIdx.x; i < 3 * n_batch; i += 16 * kHeavyRuns) idx[i] = idx32[i];
+  __syncthreads();
+  const int k = threadIdx.x >> 4, l = threadIdx.x & 15, q = k & 3;
+  for (int h = blockIdx.x; h < n_heavy; h += kHeavyBlocks) {
+    const int e_all = min(max(heavy[1 + h], 0), 3 * n_batch - 1);
+    const bool user = e_all < n_batch;
+    const int e = user ? e_all : e_all - n_batch, m = user ? n_batch : 2 * n_batch;
     const int *list = user ? idx : idx + n_batch;
-    int left = c - 1;
-    for (int j0 = (e + 1) & ~15; left > 0 && j0 < m; j0 += 16) {
+    const int row = list[e];
+    const f32x4 *G = reinterpret_cast<const f32x4 *>(scratch) + (user ? (size_t)0 : (size_t)n_batch * 16);
+    const int e0 = e & ~15, steps = (m - e0 + 15) >> 4;
+    const int run = ((steps + kHeavyRuns - 1) / kHeavyRuns) << 4;  // entries per run: whole 16-entry steps
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int n_loss = 0;
+    for (int j0 = e0 + k * run; j0 < min(m, e0 + (k + 1) * run); j0 += 16) {
       const int j = j0 + l;
-      const bool hit = j > e && j < m && list[j] == row;
+      const bool hit = j >= e && j < m && list[j] == row;
       unsigned mask = (unsigned)(__ballot(hit) >> (16 * q)) & 0xffffu;
       while (mask) {
         const int jj = j0 + __builtin_ctz(mask);
         mask &= mask - 1;
         acc += G[(size_t)jj * 16 + l];
         n_loss += (user || jj < n_batch) ? 1 : 0;
-        --left;
       }
     }
-  }
-  f32x4 *DU = reinterpret_cast<f32x4 *>(d_ui);
-  DU[(size_t)trow * 16 + l] = acc;
-  if (user) {
-    reinterpret_cast<f32x4 *>(d_out_u)[(size_t)row * 16 + l] = acc;
-    if (l == 0) d_rl_u[row] = (g[0] + g[3]) * n_loss / n_batch;
-  } else {
-    reinterpret_cast<f32x4 *>(d_out_i)[(size_t)row * 16 + l] = acc;
-    if (l == 0) d_rl_i[row] = (g[0] + g[3]) * n_loss / n_batch;
+    red[k][l] = acc;
+    if (l == 0) red_n[k] = n_loss;
+    __syncthreads();
+    if (k == 0) {
+      f32x4 sum = red[0][l];
+      int nl = red_n[0];
+#pragma unroll 8
+      for (int r = 1; r < kHeavyRuns; ++r) { sum += red[r][l]; nl += red_n[r]; }
+      const int trow = user ? row : n_user + row;
+      reinterpret_cast<f32x4 *>(d_ui)[(size_t)trow * 16 + l] = sum;
+      reinterpret_cast<f32x4 *>(user ? d_out_u : d_out_i)[(size_t)row * 16 + l] = sum;
+      if (l == 0) (user ? d_rl_u : d_rl_i)[row] = (g[0] + g[3]) * nl / n_batch;
+    }
+    __syncthreads();
   }
 }
 
@@ -244,17 +272,21 @@ extern "C" int dg_rec_head_bwd(const float *ui, const float *out_u, const float 
     return dg_fail(DG_ERR_ARG, "dg_rec_head_bwd: gradient tables and scratch must be 16-byte aligned");
   const int n_rows = n_user + n_item;
   int *tag = row_tags, *cnt = row_tags + n_rows, *slots = row_tags + 2 * (size_t)n_rows;
+  // rows named more than kSlots times: a counter and a list behind the int32 copy of the index lists
+  int *heavy = reinterpret_cast<int *>(scratch + (size_t)3 * n_batch * (DG_D + 1));
+  DG_HIP(hipMemsetAsync(heavy, 0, sizeof(int), (hipStream_t)stream));
   hipLaunchKernelGGL(head_bwd_entries_kernel, dim3((n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ui, out_u, out_i,
                      ancs, poss, negs, n_batch, n_user, n_rows, batch_div, reg_coef, entries_f, g, scratch, tag, cnt, slots);
+  hipLaunchKernelGGL(head_scatter_kernel, dim3((3 * n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, n_batch, n_user, g,
+                     scratch, tag, cnt, slots, heavy, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
   static bool attr_set = false;  // more than 64 KiB of dynamic LDS has to be opted into once
   if (!attr_set) {
-    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                3 * kMaxBatch * (int)sizeof(int)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(head_scatter_kernel, dim3((3 * n_batch + 15) / 16), dim3(256), 3 * (size_t)n_batch * sizeof(int),
-                     (hipStream_t)stream, ancs, poss, negs,
-                     n_batch, n_user, g, scratch, tag, cnt, slots, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
+  hipLaunchKernelGGL(head_heavy_kernel, dim3(kHeavyBlocks), dim3(16 * kHeavyRuns), 3 * (size_t)n_batch * sizeof(int), (hipStream_t)stream,
+                     n_batch, n_user, g, scratch, heavy, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
   DG_HIP(hipGetLastError());
   return 0;
 }

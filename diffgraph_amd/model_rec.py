@@ -26,7 +26,7 @@ from .layers import DGLLayer
 
 DEFAULT_ARGS = SimpleNamespace(latdim=64, gcn_layer=2, dims="[64]", d_emb_size=8, norm=True, steps=200,
                                noise_scale=1e-4, noise_min=1e-4, noise_max=1e-3, sampling_steps=0, batch=2048,
-                               reg=3e-2)  # DiffGraph-Rec/params.py:5-39
+                               reg=3e-2, lr=1e-3, tstBat=1024, topk=20, epoch=100, patience=20)  # DiffGraph-Rec/params.py:5-39
 
 
 def pairPredict(ancEmbeds, posEmbeds, negEmbeds):  # DiffGraph-Rec/Utils/Utils.py:4-8

@@ -505,7 +505,7 @@ def rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user: int, batch_div: flo
     tags = zero[2 * tb + 8 * n:].view(torch.int32)   # 2 n zeroed words, then 6 n slot words
     d_out_u, d_out_i = d_out[:n_user], d_out[n_user:]
     d_rl_u, d_rl_i = d_rl[:n_user], d_rl[n_user:]
-    scratch = torch.empty(3 * B * (DG_D + 1), dtype=torch.float32, device=dev)
+    scratch = torch.empty(3 * B * (DG_D + 1) + B + 4, dtype=torch.float32, device=dev)
     rc = _lib.load().dg_rec_head_bwd(ui.data_ptr(), out_u.data_ptr(), out_i.data_ptr(), ancs.data_ptr(), poss.data_ptr(),
                                      negs.data_ptr(), B, n_user, n_item, float(batch_div), float(reg), DG_D, ent_f.data_ptr(),
                                      g.data_ptr(), scratch.data_ptr(), tags.data_ptr(), d_ui.data_ptr(), d_out_u.data_ptr(),

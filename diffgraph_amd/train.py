@@ -1,0 +1,159 @@
+"""Coach of the reference's DiffGraph-Rec/main.py:34-215 -- trainEpoch / testEpoch / run -- over the HIP path.
+
+What differs from the reference's loop, and why the results do not:
+* the training triples never leave the GPU: negSampling() is one kernel, the epoch's shuffled order one randperm,
+  a step's (ancs, poss, negs) a slice of the shuffled table taken inside the recorded step;
+* a step (cal_loss, backward, Adam) is captured once per batch size as a HIP graph and replayed -- two recordings:
+  the full batch and the epoch's short last batch;
+* the reference reads three losses back per step (`.item()`, main.py:122-124); here they are added up on the device
+  and read once per epoch -- the same sums in the same order, in the losses' own precision (float64).
+The handler is any object with userNum, itemNum, target_adj, behavior_mats (CSRGraph), trn_data (PairwiseTrnData)
+and tst_data (AllRankTestData): the fields Coach and HGDM read from the reference's DataHandler.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import evaluate, io
+from .model_rec import DEFAULT_ARGS, HGDM
+from .optim import Adam
+
+
+class Coach:
+    def __init__(self, handler, args=None, device="cuda", use_graph: bool = True, seed: int = 0):
+        self.handler, self.args, self.device = handler, args or DEFAULT_ARGS, torch.device(device)
+        self.use_graph = use_graph
+        self.metrics: Dict[str, list] = dict()
+        self.model: Optional[HGDM] = None
+        self.opt: Optional[Adam] = None
+        self._graphs = {}
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(seed)
+
+    # ------------------------------------------------------------------ main.py:102-105
+    def prepareModel(self) -> None:
+        self.model = HGDM(self.handler, self.args, device=self.device).eval()   # dropout off: see HGDM.cal_loss
+        self.opt = Adam(self.model, lr=self.args.lr, weight_decay=0)
+        self._sums = torch.zeros(3, dtype=torch.float64, device=self.device)        # Loss, recLoss, diffLoss
+        n = len(self.handler.trn_data)
+        self._epoch = torch.zeros((3, n), dtype=torch.int64, device=self.device)     # the epoch's shuffled triples
+        self._batch_no = torch.zeros(1, dtype=torch.int64, device=self.device)       # advanced by every recorded step
+        self._graphs = {}     # batch size -> (recorded step, positions of the batch's pairs inside a batch)
+
+    def _step(self, ancs, poss, negs) -> None:
+        loss, bprLoss, regLoss, diff_loss = self.model.cal_loss(ancs, poss, negs)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        self._sums += torch.stack([loss.detach(), bprLoss.detach(), diff_loss.detach()]).double()
+
+    def _snapshot(self):
+        o = self.opt
+        return ([p.detach().clone() for p in self.model.parameters()], o.exp_avg.clone(), o.exp_avg_sq.clone(), o.state.clone(),
+                {p: {k: v.clone() for k, v in st.items()} for p, st in o.rest.state.items()}, self._sums.clone(),
+                self._batch_no.clone())
+
+    def _restore(self, snap) -> None:
+        """Puts the values back IN PLACE: the recorded graph holds the addresses of these tensors."""
+        params, m, v, state, rest, sums, batch_no = snap
+        o = self.opt
+        with torch.no_grad():
+            for p, q in zip(self.model.parameters(), params):
+                p.copy_(q)
+            o.exp_avg.copy_(m); o.exp_avg_sq.copy_(v); o.state.copy_(state); self._sums.copy_(sums); self._batch_no.copy_(batch_no)
+            for p, st in o.rest.state.items():      # moments the warm-up steps created start from zero
+                for k, t in st.items():
+                    t.copy_(rest[p][k]) if p in rest else t.zero_()
+
+    def _capture(self, size: int):
+        """Records one step over a batch of `size` pairs as a HIP graph.  The recording takes its triples out of the
+        epoch's table at the position a device-side batch counter names, and advances the counter: an epoch is then
+        replay after replay with nothing in between.  The warm-up steps torch asks for before a capture are real
+        steps; their effect on the model, the optimizer, the counter and the loss sums is undone afterwards."""
+        inside = torch.arange(size, dtype=torch.int64, device=self.device)
+
+        def step():
+            tri = self._epoch.index_select(1, inside + self._batch_no * self.args.batch)
+            self._batch_no.add_(1)
+            self._step(tri[0], tri[1], tri[2])
+        keep = self._snapshot()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._batch_no.zero_()
+                step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self._batch_no.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        self._restore(keep)
+        self._graphs[size] = (graph, inside)
+        return graph, inside
+
+    # ------------------------------------------------------------------ main.py:107-136
+    def trainEpoch(self) -> Dict[str, float]:
+        trn, B = self.handler.trn_data, self.args.batch
+        trn.negSampling()
+        n = len(trn)
+        steps = n // B
+        order = torch.randperm(n, device=self.device, generator=self._gen)        # DataLoader(shuffle=True)
+        epoch = torch.stack([trn.rows_dev[order].long(), trn.cols_dev[order].long(), trn.negs_dev[order].long()])
+        self._sums.zero_()
+        if self.use_graph:          # two recordings at most: the full batch and the epoch's short last one
+            self._epoch.copy_(epoch)
+            for b in range(0, n, B):
+                size = min(B, n - b)
+                graph, _ = self._graphs.get(size) or self._capture(size)
+                if b == 0:
+                    self._batch_no.zero_()
+                graph.replay()
+        else:
+            for b in range(0, n, B):
+                part = epoch[:, b: b + B].contiguous()
+                self._step(part[0], part[1], part[2])
+        ep = self._sums.cpu().tolist()                                             # the epoch's one read-back
+        div = max(steps, 1)
+        return {"Loss": ep[0] / div, "recLoss": ep[1] / div, "diffLoss": ep[2] / div}
+
+    # ------------------------------------------------------------------ main.py:138-167
+    def testEpoch(self) -> Dict[str, float]:
+        res = evaluate.testEpoch(self.model, self.handler.tst_data, self.args.topk, self.args.tstBat)
+        return {"Recall": res["Recall"], "NDCG": res["NDCG"]}
+
+    # ------------------------------------------------------------------ main.py:40-99
+    def run(self, epochs: Optional[int] = None, save_path: Optional[str] = None, log=print) -> Dict[str, float]:
+        if self.model is None:
+            self.prepareModel()
+        recallMax = ndcgMax = 0.0
+        bestEpoch = wait = 0
+        for ep in range(self.args.epoch if epochs is None else epochs):
+            reses = self.trainEpoch()
+            log("Epoch %d Train: " % ep + ", ".join("%s = %.4f" % kv for kv in reses.items()))
+            reses = self.testEpoch()
+            for k, v in reses.items():
+                self.metrics.setdefault("Test" + k, []).append(v)
+            if reses["Recall"] > recallMax:
+                recallMax, ndcgMax, bestEpoch, wait = reses["Recall"], reses["NDCG"], ep, 0
+                if save_path:
+                    self.saveModel(save_path)
+            else:
+                wait += 1
+            log("Epoch %d Test: " % ep + ", ".join("%s = %.4f" % kv for kv in reses.items()))
+            if wait >= self.args.patience:
+                log(f"Early stop at epoch {ep}, best epoch {bestEpoch}")
+                break
+        return {"bestEpoch": bestEpoch, "Recall": recallMax, "NDCG": ndcgMax}
+
+    # ------------------------------------------------------------------ main.py:196-211 (state dicts, no pickled modules)
+    def saveModel(self, path: str) -> None:
+        io.save_checkpoint(path, self.model, self.opt)
+
+    def loadModel(self, path: str) -> None:
+        if self.model is None:
+            self.prepareModel()
+        io.load_checkpoint(path, self.model, self.opt)
+        self._graphs = {}

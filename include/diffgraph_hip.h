@@ -345,9 +345,10 @@ int dg_rec_head_fwd(const float *ui, const float *out_u, const float *out_i, con
 /* Backward of dg_rec_head_fwd.  g: DEVICE fp64[4] = dL/d{loss,bpr,reg,diff} (what autograd hands
  * back; usually {1,0,0,0}).  Writes the dense gradient tables d_ui [n_user+n_item][64],
  * d_out_u [n_user][64], d_out_i [n_item][64], d_row_loss_u fp64[n_user], d_row_loss_i fp64[n_item]:
- * rows of batch entries get their gradient (entries that name the same row are added in batch
- * order, so the result does not depend on timing); ALL OTHER ROWS MUST BE ZERO ON ENTRY (the caller
- * clears the tables).  scratch: DEVICE float[3*n_batch*65], 16-byte aligned like the tables.
+ * rows of batch entries get their gradient (entries that name the same row are added in a fixed
+ * order -- batch order, or 64 runs of the batch for rows named more than six times -- so the result
+ * does not depend on timing); ALL OTHER ROWS MUST BE ZERO ON ENTRY (the caller clears the tables).
+ * scratch: DEVICE float[3*n_batch*65 + n_batch + 4], 16-byte aligned like the tables.
  * row_tags: DEVICE int32[8*(n_user+n_item)] whose first 2*(n_user+n_item) words are ZERO ON ENTRY
  * (per-row first-entry marks and entry counts, then six entry slots per row; left dirty). */
 int dg_rec_head_bwd(const float *ui, const float *out_u, const float *out_i, const int64_t *ancs,

@@ -311,7 +311,7 @@ def test_denoiser_weight_gradients_match_fp64(n):
                                    err_msg="grad " + nm)
 
 
-@pytest.mark.parametrize("n_batch", [1, 37, 2048])
+@pytest.mark.parametrize("n_batch", [1, 37, 2048, 8192])
 def test_rec_loss_head_matches_torch_autograd(n_batch):
     """The fused loss head (values and all five gradients) against the reference's own formulation in torch
     ops (DiffGraph-Rec/Model.py:101-111), with batch entries that name the same row many times."""
@@ -339,7 +339,8 @@ def test_rec_loss_head_matches_torch_autograd(n_batch):
 
     dl = [dev(t).requires_grad_(True) for t in (ui, out_u, out_i, rl_u, rl_i)]
     got = _RecHeadFn.apply(*dl, dev(ancs), dev(poss), dev(negs), nu, batch_div, reg)
-    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5)
+    # (the torch formulation sums 3 x n_batch x 64 squares in fp32; at 8192 entries that alone is 1e-5 off the fp64 sum)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5 if n_batch <= 2048 else 3e-5)
     (got * dev(wts)).sum().backward()
     for nm, g, w in zip(("ui", "out_u", "out_i", "row_loss_u", "row_loss_i"), dl, leaves):
         scale = float(w.grad.abs().max())
