@@ -163,17 +163,12 @@ def main():
         return
     wl, graphs, model = build_rec(workload, device)
     n = wl.n
+    gen = torch.Generator().manual_seed(1)
     B = model.args.batch
-    # a real batch: shuffled pairs of the target behaviour with one sampled negative each, as trainEpoch feeds them
-    # (popular items are named by many entries of a batch; uniform random indices would hide that)
-    import scipy.sparse as sp
-    from diffgraph_amd.sampling import PairwiseTrnData
-    tu, ti = wl.target
-    trn = PairwiseTrnData(sp.coo_matrix((np.ones(len(tu), np.float32), (tu, ti)), shape=(wl.n_user, wl.n_item)), device=device, seed=1)
-    trn.negSampling()
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1)
-    ancs, poss, negs = next(trn.batches(B, shuffle=True, generator=gen))
+    # (uniform random triples; `--workload epoch_tmall` runs whole epochs over the real, popularity-skewed pairs)
+    ancs = torch.randint(0, wl.n_user, (B,), generator=gen).to(device)
+    poss = torch.randint(0, wl.n_item, (B,), generator=gen).to(device)
+    negs = torch.randint(0, wl.n_item, (B,), generator=gen).to(device)
 
     timer = LayerTimer()
     model.layer_hook = timer
