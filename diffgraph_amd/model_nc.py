@@ -129,7 +129,12 @@ class HGDM(nn.Module):
                 prev[g] = e_out
                 saved[g].append(e_out)
                 norms[g].append(rn)
+            hook = getattr(self, "layer_hook", None)     # timing hook, as in the Rec model
+            if hook is not None:
+                hook("begin", l)
             _launch_distinct(tasks, ops.gcn_layer_batched)
+            if hook is not None:
+                hook("end", l)
         return sums, saved, norms
 
     def forward(self, he_adjs, feature_list, is_training=True):
