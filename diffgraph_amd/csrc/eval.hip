@@ -29,7 +29,7 @@ constexpr int kUsersPerBlock = 128;      // 4 wavefronts x 32 users
 constexpr int kTile = 32;                // items per tile
 constexpr int kPitch = 68;               // floats per staged item row (64 + 4: conflict-free ds_read_b128)
 constexpr float kMasked = -1e8f;         // main.py:157
-constexpr int kBuf = 8;                  // parked candidates per lane between two list merges
+constexpr int kBuf = 16;                 // parked candidates per lane between two list merges (two half tiles)
 
 struct topk_args {
   const float *usr_emb, *item_emb;
@@ -49,7 +49,7 @@ __device__ __forceinline__ int lower_bound(const int32_t *__restrict__ col, int 
   return b;
 }
 
-// KPAD: list slots per lane (k rounded up to a multiple of 8).  The list lives in registers, sorted by
+// KPAD: list slots per lane (k rounded up to a multiple of 4).  The list lives in registers, sorted by
 // falling score; slots [0, KPAD - k) hold +inf and never move, so the lane's worst entry is always
 // the last slot.  A new score enters through a compare-and-shift over all slots (no indexed access).
 template <int KPAD>
@@ -79,8 +79,17 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
   // Scores that beat the list's last entry are parked in a small per-lane buffer (LDS, in the order seen)
   // and merged into the lists by ALL lanes together whenever some lane's buffer is full: the
   // compare-and-shift network then runs for 64 lanes at once instead of once per lucky lane.
+  // A score can only be among the user's k best if it beats the lane's worst entry, is not below the worst entry of
+  // the list the other half-wavefront keeps for the same user over the other items of each tile, and is not below
+  // the smaller of the two lists' ceil(k/2)-th entries (the two lists together hold k entries at least that good).
+  // The lists change only in compact(), for all lanes at once, so the largest of the three bounds is worked out
+  // there and a tile costs ONE compare per score.  (VALU and MFMA instructions do not overlap on this chip -- the
+  // co-execution counter stays at zero -- so every VALU instruction per tile adds to the kernel's time.)
+  float bound = valid ? -INFINITY : INFINITY;
+  const int mid_slot = KPAD - k + (k + 1) / 2 - 1;
   int nb = 0;
   auto compact = [&]() {
+#pragma nounroll
     for (int b = 0; b < kBuf; ++b) {
       const bool have = b < nb;
       const float s = have ? bs[b * 256 + tid] : -INFINITY;
@@ -100,6 +109,12 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
       }
     }
     nb = 0;
+    float mid = ls[KPAD - 1];
+#pragma unroll
+    for (int p = 0; p < KPAD - 1; ++p) mid = p == mid_slot ? ls[p] : mid;
+    const float tau = ls[KPAD - 1];
+    const float other = fmaxf(__shfl_xor(tau, 32), fminf(mid, __shfl_xor(mid, 32)));
+    bound = valid ? fmaxf(tau, other) : INFINITY;
   };
 
   const int tile0 = blockIdx.y * a.tiles_per_split;
@@ -162,22 +177,22 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
       for (int r = 0; r < 16; ++r)
         if (item0 + 8 * (r >> 2) + 4 * h + (r & 3) >= a.n_item) acc[r] = -INFINITY;
     }
-    // the other half-wavefront holds the same user's list over the other items of each tile: nothing
-    // below ITS worst entry can be among the user's k best either
-    const float tau = ls[KPAD - 1], tau_other = __shfl_xor(tau, 32);
-    float best = acc[0];
+    // Park what may be among the k best (>= : a score equal to the other list's bound may still win there on the
+    // item id; one equal to the lane's own worst entry is dropped again by compact()).  Two halves of eight scores,
+    // so that room for a whole half is made at most once per half.
 #pragma unroll
-    for (int r = 1; r < 16; ++r) best = fmaxf(best, acc[r]);
-    if (__any(valid && best > tau && best >= tau_other)) {
+    for (int half = 0; half < 2; ++half) {
+      if (__any(nb > kBuf - 8)) compact();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // equal scores: the earlier (lower) item id stays, so a new one has to be strictly better
-        const bool cand = valid && acc[r] > tau && acc[r] >= tau_other;
-        if (__any(cand && nb >= kBuf)) compact();
-        if (cand) {  // parked; merged into the list at the next compaction
-          bs[nb * 256 + tid] = acc[r];
-          bi[nb * 256 + tid] = item0 + 8 * (r >> 2) + 4 * h + (r & 3);
-          ++nb;
+      for (int r = 0; r < 8; ++r) {
+        const int rr = 8 * half + r;
+        const bool cand = acc[rr] >= bound;
+        if (__any(cand)) {
+          if (cand) {
+            bs[nb * 256 + tid] = acc[rr];
+            bi[nb * 256 + tid] = item0 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+            ++nb;
+          }
         }
       }
     }
@@ -262,19 +277,20 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(const int32_t *__rest
   ndcg[u] = tst_num > 0 ? dcg / max_dcg[min(tst_num, k)] : 0.0;
 }
 
-// Item-range splits per user tile: about 1.5 workgroups per CU, at most 8 (every split keeps its own
-// candidate lists, and a list over fewer items is replaced more often per item).
-int pick_split(int32_t n_test, int32_t n_item) {
+// Item-range splits per user tile: as many as keep all workgroups resident at once -- three per CU at the scoring
+// kernel's register count, 768 on the chip (one more split and a second, mostly empty round follows: measured 2.01 ms
+// with 750 workgroups, 2.32 ms with 1000) -- and at most 256 / k (the merge kernel takes 2 x splits x k <= 512 candidates per user).
+int pick_split(int32_t n_test, int32_t n_item, int32_t k) {
   const int tiles = (n_test + kUsersPerBlock - 1) / kUsersPerBlock;
   const int n_tiles = (n_item + kTile - 1) / kTile;
-  return std::max(1, std::min(std::min((384 + tiles - 1) / tiles, 8), n_tiles));
+  return std::max(1, std::min(std::min(768 / tiles, 256 / std::max(k, 1)), n_tiles));
 }
 
 }  // namespace
 
 extern "C" size_t dg_eval_topk_workspace(int32_t n_test, int32_t n_item, int32_t k) {
   if (n_test <= 0 || n_item <= 0 || k <= 0) return 0;
-  return (size_t)n_test * 2 * pick_split(n_test, n_item) * k * (sizeof(float) + sizeof(int32_t));
+  return (size_t)n_test * 2 * pick_split(n_test, n_item, k) * k * (sizeof(float) + sizeof(int32_t));
 }
 
 extern "C" int dg_eval_topk(const float *usr_emb, const float *item_emb, int32_t n_user, int32_t n_item,
@@ -291,7 +307,7 @@ extern "C" int dg_eval_topk(const float *usr_emb, const float *item_emb, int32_t
   const size_t need = dg_eval_topk_workspace(n_test, n_item, k);
   if (workspace_bytes < need) return dg_fail(DG_ERR_SIZE, "dg_eval_topk: workspace of %zu bytes, %zu needed", workspace_bytes, need);
   const int tiles = (n_test + kUsersPerBlock - 1) / kUsersPerBlock;
-  const int n_split = pick_split(n_test, n_item);
+  const int n_split = pick_split(n_test, n_item, k);
   const int n_tiles = (n_item + kTile - 1) / kTile;
   topk_args a;
   a.usr_emb = usr_emb; a.item_emb = item_emb; a.test_users = test_users; a.trn_rowptr = trn_rowptr; a.trn_col = trn_col;
@@ -299,9 +315,10 @@ extern "C" int dg_eval_topk(const float *usr_emb, const float *item_emb, int32_t
   a.cand_idx = (int32_t *)(a.cand_score + (size_t)n_test * 2 * n_split * k);
   a.n_test = n_test; a.n_item = n_item; a.k = k; a.n_split = n_split;
   a.tiles_per_split = (n_tiles + n_split - 1) / n_split;
-  const int kpad = (k + 7) / 8 * 8;
-  void (*kern)(const topk_args) = kpad == 8 ? score_topk_kernel<8> : kpad == 16 ? score_topk_kernel<16>
-                                  : kpad == 24 ? score_topk_kernel<24> : score_topk_kernel<32>;
+  static void (*const kerns[8])(const topk_args) = {score_topk_kernel<4>,  score_topk_kernel<8>,  score_topk_kernel<12>,
+                                                     score_topk_kernel<16>, score_topk_kernel<20>, score_topk_kernel<24>,
+                                                     score_topk_kernel<28>, score_topk_kernel<32>};
+  void (*kern)(const topk_args) = kerns[(k + 3) / 4 - 1];  // list slots: k rounded up to a multiple of 4
   hipLaunchKernelGGL(kern, dim3(tiles, n_split), dim3(256), 0, (hipStream_t)stream, a);
   const int n_cand = 2 * n_split * k;
   auto merge = n_cand <= 128 ? merge_topk_kernel<2> : n_cand <= 256 ? merge_topk_kernel<4> : merge_topk_kernel<8>;  // <= 512
