@@ -108,11 +108,13 @@ def calcRes(topLocs: torch.Tensor, data: AllRankTestData, batIds: torch.Tensor):
                                      _lib.stream_ptr(dev))
     _lib.check(rc, "dg_eval_metrics")
     r, d = recall.cpu().numpy(), ndcg.cpu().numpy()
-    allRecall = allNdcg = 0
-    for a, b in zip(r.tolist(), d.tolist()):
-        allRecall += a
-        allNdcg += b
-    return allRecall, allNdcg, r, d
+    return _seq_sum(r), _seq_sum(d), r, d
+
+
+def _seq_sum(v: np.ndarray) -> float:
+    """v[0] + v[1] + ... added one after the other in float64, as the reference's `+=` loops add them (np.cumsum is
+    sequential; np.sum adds pairwise and can differ in the last bit)."""
+    return float(np.cumsum(v, dtype=np.float64)[-1]) if v.size else 0
 
 
 def testEpoch(model, data: AllRankTestData, topk: int = 20, tstBat: int = 1024) -> Dict[str, float]:
@@ -130,10 +132,6 @@ def rank_metrics(usrEmbeds, itmEmbeds, data: AllRankTestData, topk: int = 20, ts
     _, _, r, d = calcRes(topLocs, data, data.test_users_dev)
     epRecall = epNdcg = 0
     for b in range(0, num, tstBat):
-        recall = ndcg = 0
-        for a, c in zip(r[b: b + tstBat].tolist(), d[b: b + tstBat].tolist()):
-            recall += a
-            ndcg += c
-        epRecall += recall
-        epNdcg += ndcg
+        epRecall += _seq_sum(r[b: b + tstBat])
+        epNdcg += _seq_sum(d[b: b + tstBat])
     return {"Recall": epRecall / num, "NDCG": epNdcg / num, "topLocs": topLocs, "recall_per_user": r, "ndcg_per_user": d}
