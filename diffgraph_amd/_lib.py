@@ -62,6 +62,13 @@ class LossTask(C.Structure):
                 ("xn", C.c_void_p)]
 
 
+class WgradTask(C.Structure):
+    _fields_ = [("dn", C.POINTER(Denoiser)), ("ts", C.c_void_p), ("dout_tot", C.c_void_p), ("hid", C.c_void_p),
+                ("dpre", C.c_void_p), ("xn", C.c_void_p), ("n", C.c_int64), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("d_w_emb", C.c_void_p), ("d_b_emb", C.c_void_p), ("d_w_in", C.c_void_p),
+                ("d_b_in", C.c_void_p), ("d_w_out", C.c_void_p), ("d_b_out", C.c_void_p)]
+
+
 # name -> (restype, argtypes); one entry per symbol declared in include/diffgraph_hip.h
 SIGNATURES = {
     "dg_version": (C.c_int, []),
@@ -104,6 +111,7 @@ SIGNATURES = {
     "dg_denoiser_wgrad_workspace": (C.c_size_t, [C.c_int32]),
     "dg_denoiser_wgrad": (C.c_int, [C.POINTER(Denoiser), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_size_t] + [C.c_void_p] * 7),
+    "dg_denoiser_wgrad_batched": (C.c_int, [C.POINTER(WgradTask), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dg_eval_topk_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "dg_eval_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),

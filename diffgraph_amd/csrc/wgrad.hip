@@ -43,10 +43,20 @@ struct tab_args {
   const float *w_emb, *b_emb;
   float freqs[4];
   int32_t n_steps;
+  float *tab;
+};
+
+// Up to kMaxTasks denoisers per launch (the user and the item denoiser of a training step): blockIdx.y picks one.
+constexpr int kMaxTasks = 2;
+template <typename T>
+struct per_task {
+  T t[kMaxTasks];
 };
 
 // tab[t] = [ emb_layer(te_t) | te_t ],  te_t = [cos(t f_0..3), sin(t f_0..3)]  (Model.py:215-218)
-__global__ __launch_bounds__(256) void wgrad_tab_kernel(tab_args a, float *__restrict__ tab) {
+__global__ __launch_bounds__(256) void wgrad_tab_kernel(const per_task<tab_args> all) {
+  const tab_args &a = all.t[blockIdx.y];
+  float *__restrict__ tab = a.tab;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= a.n_steps) return;
   float te[8];
@@ -111,7 +121,8 @@ __device__ __forceinline__ wg_operands load_operands(const wg_args &a, const flo
 // colsum(dpre).  The four waves of a half take every fourth 4-row quad of the workgroup's strip
 // (the next quad's rows are requested before the current one is multiplied) and hand their sums
 // to the half's first wave through LDS, one after the other.
-__global__ __launch_bounds__(512) void wgrad_partial_kernel(const wg_args a) {
+__global__ __launch_bounds__(512) void wgrad_partial_kernel(const per_task<wg_args> all) {
+  const wg_args &a = all.t[blockIdx.y];
   __shared__ f32x4 xch[2][21][64];  // per half: 16 + 4 + 1 accumulator float4s per lane
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = wave >> 2, sub = wave & 3;
   const int j = lane & 15, k = lane >> 4;
@@ -191,7 +202,8 @@ struct fin_args {
 
 // A workgroup finishes 32 floats of the result: thread (slice, f) adds 1/8 of the kGroups partials of
 // float f in order, then the eight slice sums are added in slice order -- a fixed order overall.
-__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const fin_args a) {
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const per_task<fin_args> all) {
+  const fin_args &a = all.t[blockIdx.y];
   __shared__ float part[8][32];
   const int slice = threadIdx.x >> 5, f = blockIdx.x * 32 + (threadIdx.x & 31);
   float s = 0.f;
@@ -215,9 +227,15 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const fin_args a) {
 }
 
 // dW_emb[e][c] = sum_o W_in[o][64+e] mk[o][c];  db_emb[e] = sum_o W_in[o][64+e] db_in[o]
-__global__ __launch_bounds__(128) void wgrad_emb_kernel(const float *__restrict__ w_in, const float *__restrict__ mk,
-                                                        const float *__restrict__ d_b_in, float *__restrict__ d_w_emb,
-                                                        float *__restrict__ d_b_emb) {
+struct emb_args {
+  const float *w_in, *mk, *d_b_in;
+  float *d_w_emb, *d_b_emb;
+};
+
+__global__ __launch_bounds__(128) void wgrad_emb_kernel(const per_task<emb_args> all) {
+  const emb_args &a = all.t[blockIdx.y];
+  const float *__restrict__ w_in = a.w_in, *__restrict__ mk = a.mk, *__restrict__ d_b_in = a.d_b_in;
+  float *__restrict__ d_w_emb = a.d_w_emb, *__restrict__ d_b_emb = a.d_b_emb;
   const int t = threadIdx.x;
   if (t < 64) {
     const int e = t >> 3, c = t & 7;
@@ -239,38 +257,63 @@ extern "C" size_t dg_denoiser_wgrad_workspace(int32_t n_steps) {
   return ((size_t)n_steps * kTabCols + 64 * 8 + (size_t)kGroups * kPartFloats) * sizeof(float);
 }
 
+extern "C" int dg_denoiser_wgrad_batched(const dg_wgrad_task *tasks, int32_t n_tasks, int32_t n_steps, int32_t d,
+                                         void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_denoiser_wgrad: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!tasks || n_tasks <= 0 || n_tasks > kMaxTasks)
+    return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: n_tasks must be in [1,%d] (got %d)", kMaxTasks, n_tasks);
+  if (n_steps <= 0) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: bad sizes");
+  per_task<tab_args> ta;
+  per_task<wg_args> wa;
+  per_task<fin_args> fa;
+  per_task<emb_args> ea;
+  for (int k = 0; k < n_tasks; ++k) {
+    const dg_wgrad_task &t = tasks[k];
+    const dg_denoiser *dn = t.dn;
+    if (!dn || !dn->w_emb || !dn->b_emb || !dn->w_in || !dn->freqs_host || !t.ts || !t.dout_tot || !t.hid || !t.dpre || !t.xn ||
+        !t.workspace || !t.d_w_emb || !t.d_b_emb || !t.d_w_in || !t.d_b_in || !t.d_w_out || !t.d_b_out)
+      return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: NULL argument (task %d)", k);
+    if (t.n < 0) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: bad sizes (task %d)", k);
+    if (t.workspace_bytes < dg_denoiser_wgrad_workspace(n_steps))
+      return dg_fail(DG_ERR_SIZE, "dg_denoiser_wgrad: workspace of %zu bytes, %zu needed", t.workspace_bytes,
+                     dg_denoiser_wgrad_workspace(n_steps));
+    if (((uintptr_t)t.dout_tot | (uintptr_t)t.hid | (uintptr_t)t.dpre | (uintptr_t)t.xn | (uintptr_t)t.workspace) & 15)
+      return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: tables and workspace must be 16-byte aligned");
+    for (int j = 0; j < k; ++j)
+      if (tasks[j].workspace == t.workspace) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: tasks %d and %d share a workspace", j, k);
+    float *tab = (float *)t.workspace;
+    float *mk = tab + (size_t)n_steps * kTabCols;
+    float *partials = mk + 64 * 8;
+    tab_args &a = ta.t[k];
+    a.w_emb = dn->w_emb; a.b_emb = dn->b_emb; a.n_steps = n_steps; a.tab = tab;
+    for (int f = 0; f < 4; ++f) a.freqs[f] = dn->freqs_host[f];
+    wg_args &w = wa.t[k];
+    w.dout = t.dout_tot; w.hid = t.hid; w.dpre = t.dpre; w.xn = t.xn; w.ts = t.ts; w.tab = tab; w.partials = partials;
+    w.n = t.n; w.n_steps = n_steps;
+    w.rows_per_group = ((t.n + kGroups - 1) / kGroups + 15) / 16 * 16;
+    if (w.rows_per_group == 0) w.rows_per_group = 16;
+    fin_args &f = fa.t[k];
+    f.partials = partials; f.d_w_in = t.d_w_in; f.d_b_in = t.d_b_in; f.d_w_out = t.d_w_out; f.d_b_out = t.d_b_out; f.mk = mk;
+    emb_args &e = ea.t[k];
+    e.w_in = dn->w_in; e.mk = mk; e.d_b_in = t.d_b_in; e.d_w_emb = t.d_w_emb; e.d_b_emb = t.d_b_emb;
+  }
+  for (int k = n_tasks; k < kMaxTasks; ++k) { ta.t[k] = ta.t[0]; wa.t[k] = wa.t[0]; fa.t[k] = fa.t[0]; ea.t[k] = ea.t[0]; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_tab_kernel, dim3((n_steps + 255) / 256, n_tasks), dim3(256), 0, s, ta);
+  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(kGroups, n_tasks), dim3(512), 0, s, wa);
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((kPartFloats + 31) / 32, n_tasks), dim3(256), 0, s, fa);
+  hipLaunchKernelGGL(wgrad_emb_kernel, dim3(1, n_tasks), dim3(128), 0, s, ea);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int dg_denoiser_wgrad(const dg_denoiser *dn, int32_t n_steps, const int64_t *ts, const float *dout_tot,
                                  const float *hid, const float *dpre, const float *xn, int64_t n, int32_t d,
                                  void *workspace, size_t workspace_bytes, float *d_w_emb, float *d_b_emb, float *d_w_in,
                                  float *d_b_in, float *d_w_out, float *d_b_out, void *stream) {
-  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_denoiser_wgrad: embedding width %d unsupported (built for %d)", d, DG_D);
-  if (!dn || !dn->w_emb || !dn->b_emb || !dn->w_in || !dn->freqs_host || !ts || !dout_tot || !hid || !dpre || !xn ||
-      !workspace || !d_w_emb || !d_b_emb || !d_w_in || !d_b_in || !d_w_out || !d_b_out)
-    return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: NULL argument");
-  if (n_steps <= 0 || n < 0) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: bad sizes");
-  if (workspace_bytes < dg_denoiser_wgrad_workspace(n_steps))
-    return dg_fail(DG_ERR_SIZE, "dg_denoiser_wgrad: workspace of %zu bytes, %zu needed", workspace_bytes,
-                   dg_denoiser_wgrad_workspace(n_steps));
-  if (((uintptr_t)dout_tot | (uintptr_t)hid | (uintptr_t)dpre | (uintptr_t)xn | (uintptr_t)workspace) & 15)
-    return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad: tables and workspace must be 16-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
-  float *tab = (float *)workspace;
-  float *mk = tab + (size_t)n_steps * kTabCols;
-  float *partials = mk + 64 * 8;
-  tab_args ta;
-  ta.w_emb = dn->w_emb; ta.b_emb = dn->b_emb; ta.n_steps = n_steps;
-  for (int k = 0; k < 4; ++k) ta.freqs[k] = dn->freqs_host[k];
-  hipLaunchKernelGGL(wgrad_tab_kernel, dim3((n_steps + 255) / 256), dim3(256), 0, s, ta, tab);
-  wg_args a;
-  a.dout = dout_tot; a.hid = hid; a.dpre = dpre; a.xn = xn; a.ts = ts; a.tab = tab; a.partials = partials;
-  a.n = n; a.n_steps = n_steps;
-  a.rows_per_group = ((n + kGroups - 1) / kGroups + 15) / 16 * 16;
-  if (a.rows_per_group == 0) a.rows_per_group = 16;
-  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(kGroups), dim3(512), 0, s, a);
-  fin_args f;
-  f.partials = partials; f.d_w_in = d_w_in; f.d_b_in = d_b_in; f.d_w_out = d_w_out; f.d_b_out = d_b_out; f.mk = mk;
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((kPartFloats + 31) / 32), dim3(256), 0, s, f);
-  hipLaunchKernelGGL(wgrad_emb_kernel, dim3(1), dim3(128), 0, s, dn->w_in, mk, d_b_in, d_w_emb, d_b_emb);
-  DG_HIP(hipGetLastError());
-  return 0;
+  dg_wgrad_task t;
+  t.dn = dn; t.ts = ts; t.dout_tot = dout_tot; t.hid = hid; t.dpre = dpre; t.xn = xn; t.n = n;
+  t.workspace = workspace; t.workspace_bytes = workspace_bytes;
+  t.d_w_emb = d_w_emb; t.d_b_emb = d_b_emb; t.d_w_in = d_w_in; t.d_b_in = d_b_in; t.d_w_out = d_w_out; t.d_b_out = d_b_out;
+  return dg_denoiser_wgrad_batched(&t, 1, n_steps, d, stream);
 }

@@ -135,10 +135,8 @@ class _RecLossFn(torch.autograd.Function):
                                                   float(args.reg), ent_f, g.contiguous(), full=True)
         d_het, d_ui, dout, hid, dpre, xn = ops.diffusion_loss_bwd_spans(spans, ui, het, noise, ts, sa, sb, lw, d_rl, d_out,
                                                                         d_target_add=d_ui_head)
-        grads = []
-        for sp in spans:
-            r = slice(sp.begin, sp.begin + sp.n)
-            grads += list(ops.denoiser_wgrad(sp.dn, gd.steps, ts[r], dout[r], hid[r], dpre[r], xn[r]))
+        jobs = [(sp.dn,) + tuple(t[sp.begin: sp.begin + sp.n] for t in (ts, dout, hid, dpre, xn)) for sp in spans]
+        grads = [g for res in ops.denoiser_wgrad_many(jobs, gd.steps) for g in res]   # both denoisers, one set of launches
         return (d_ui, d_het, None, None, None, None, None, None, None) + tuple(grads)
 
 

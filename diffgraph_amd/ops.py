@@ -436,25 +436,36 @@ def diffusion_loss_bwd_spans(spans: Sequence[LossSpan], target, x_start, noise, 
 def denoiser_wgrad(dn: DenoiserParams, n_steps: int, ts, dout, hid, dpre, xn):
     """Weight gradients of the denoiser from the tables of diffusion_loss_bwd.
     Returns (d_w_emb [8,8], d_b_emb [8], d_w_in [64,72], d_b_in [64], d_w_out [64,64], d_b_out [64])."""
-    n = dout.shape[0]
-    for nm, t in (("dout", dout), ("hid", hid), ("dpre", dpre), ("xn", xn)):
-        _table(t, nm, n)
-    _vec(ts, "timesteps", torch.int64, n)
+    return denoiser_wgrad_many([(dn, ts, dout, hid, dpre, xn)], n_steps)[0]
+
+
+def denoiser_wgrad_many(jobs, n_steps: int):
+    """denoiser_wgrad for up to two denoisers -- jobs: (dn, ts, dout, hid, dpre, xn) each -- in one set of launches.
+    Returns one 6-tuple of gradients per job."""
     lib = _lib.load()
-    dev = dout.device
     ws_bytes = int(lib.dg_denoiser_wgrad_workspace(n_steps))
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
-    flat = torch.empty(64 + 8 + DG_D * 72 + DG_D + DG_D * DG_D + DG_D, dtype=torch.float32, device=dev)
-    parts, o = [], 0
-    for shape in ((8, 8), (8,), (DG_D, 72), (DG_D,), (DG_D, DG_D), (DG_D,)):
-        k = math.prod(shape)
-        parts.append(flat[o: o + k].view(shape))
-        o += k
-    rc = lib.dg_denoiser_wgrad(C.byref(dn.c), n_steps, ts.data_ptr(), dout.data_ptr(), hid.data_ptr(), dpre.data_ptr(),
-                               xn.data_ptr(), n, DG_D, ws.data_ptr(), ws_bytes, *[p.data_ptr() for p in parts],
-                               _lib.stream_ptr(dev))
-    _lib.check(rc, "dg_denoiser_wgrad")
-    return tuple(parts)
+    arr = (_lib.WgradTask * len(jobs))()
+    results, keep = [], []
+    for k, (dn, ts, dout, hid, dpre, xn) in enumerate(jobs):
+        n = dout.shape[0]
+        for nm, t in (("dout", dout), ("hid", hid), ("dpre", dpre), ("xn", xn)):
+            _table(t, nm, n)
+        _vec(ts, "timesteps", torch.int64, n)
+        dev = dout.device
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        flat = torch.empty(64 + 8 + DG_D * 72 + DG_D + DG_D * DG_D + DG_D, dtype=torch.float32, device=dev)
+        parts, o = [], 0
+        for shape in ((8, 8), (8,), (DG_D, 72), (DG_D,), (DG_D, DG_D), (DG_D,)):
+            m = math.prod(shape)
+            parts.append(flat[o: o + m].view(shape))
+            o += m
+        arr[k] = _lib.WgradTask(C.pointer(dn.c), ts.data_ptr(), dout.data_ptr(), hid.data_ptr(), dpre.data_ptr(), xn.data_ptr(),
+                                n, ws.data_ptr(), ws_bytes, *[p.data_ptr() for p in parts])
+        keep.append(ws)
+        results.append(tuple(parts))
+    rc = lib.dg_denoiser_wgrad_batched(arr, len(jobs), n_steps, DG_D, _lib.stream_ptr(jobs[0][2].device))
+    _lib.check(rc, "dg_denoiser_wgrad_batched")
+    return results
 
 
 # ------------------------------------------------------------------------------ loss head (a10)

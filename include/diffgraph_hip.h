@@ -320,6 +320,20 @@ int dg_denoiser_wgrad(const dg_denoiser *dn, int32_t n_steps, const int64_t *ts,
                       void *workspace, size_t workspace_bytes, float *d_w_emb, float *d_b_emb,
                       float *d_w_in, float *d_b_in, float *d_w_out, float *d_b_out, void *stream);
 
+/* The same for up to two denoisers (a training step's usr_denoiser and item_denoiser,
+ * DiffGraph-Rec/Model.py:34-35) in one set of four launches; every task brings its own workspace. */
+typedef struct dg_wgrad_task {
+  const dg_denoiser *dn;
+  const int64_t *ts;
+  const float *dout_tot, *hid, *dpre, *xn;
+  int64_t n;
+  void *workspace;
+  size_t workspace_bytes;
+  float *d_w_emb, *d_b_emb, *d_w_in, *d_b_in, *d_w_out, *d_b_out;
+} dg_wgrad_task;
+int dg_denoiser_wgrad_batched(const dg_wgrad_task *tasks, int32_t n_tasks, int32_t n_steps, int32_t d,
+                              void *stream);
+
 /* ------------------------------------------------------------------------------------
  * a10: the loss head of HGDM.cal_loss (DiffGraph-Rec/Model.py:101-111; pairPredict,
  * DiffGraph-Rec/Utils/Utils.py:4-8), forward and backward.  With, per batch entry b,

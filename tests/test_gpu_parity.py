@@ -311,6 +311,24 @@ def test_denoiser_weight_gradients_match_fp64(n):
                                    err_msg="grad " + nm)
 
 
+def test_denoiser_weight_gradients_two_denoisers_one_call():
+    """Two denoisers over row spans of different length in one set of launches: the same bits as one call each."""
+    gen = torch.Generator().manual_seed(3)
+    T_ = 200
+    jobs = []
+    for n in (1000, 37):
+        dn = dg.Denoise([64, 64], [64, 64], 8, norm=True).to(DEV)
+        jobs.append((dn.params(True), dev(torch.randint(0, T_, (n,), generator=gen)))
+                    + tuple(dev(torch.randn(n, 64, generator=gen)) for _ in range(4)))
+    both = ops.denoiser_wgrad_many(jobs, T_)
+    for job, got in zip(jobs, both):
+        alone = ops.denoiser_wgrad(job[0], T_, *job[1:])
+        for g, a in zip(got, alone):
+            assert torch.equal(g, a)
+    with pytest.raises(dg.DiffGraphHipError):
+        ops.denoiser_wgrad_many(jobs + jobs[:1], T_)
+
+
 @pytest.mark.parametrize("n_batch", [1, 37, 2048, 8192])
 def test_rec_loss_head_matches_torch_autograd(n_batch):
     """The fused loss head (values and all five gradients) against the reference's own formulation in torch
