@@ -174,15 +174,13 @@ def main():
     model.layer_hook = timer
     import diffgraph_amd as dg
     opt = dg.optim.Adam(model, lr=1e-3, weight_decay=0)  # DiffGraph-Rec/main.py:117-119
+    from diffgraph_amd.train import training_step
+    seed_vec = torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=device)
 
     def step():
         # one training step as Coach.trainEpoch runs it (DiffGraph-Rec/main.py:114-128): cal_loss (timesteps
         # and noise drawn inside training_losses2, Model.py:352-353), backward, Adam
-        out = model.cal_loss(ancs, poss, negs)
-        opt.zero_grad(set_to_none=True)
-        out[0].backward()
-        opt.step()
-        return out
+        return training_step(model, opt, ancs, poss, negs, seed_vec)   # float64[4]: loss, bprLoss, regLoss, diff_loss
 
     if args.no_graph:
         run = step

@@ -220,6 +220,12 @@ class HGDM(nn.Module):
         return ui[:nu], ui[nu:], het[:nu], het[nu:]
 
     def cal_loss(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None):  # Model.py:94-111
+        res = self.cal_loss_vector(ancs, poss, negs, ts_u, noise_u, ts_i, noise_i)
+        return res[0], res[1], res[2], res[3]
+
+    def cal_loss_vector(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None) -> torch.Tensor:
+        """cal_loss as one float64[4] tensor (loss, bprLoss, regLoss, diff_loss).  `res.backward(e)` with
+        e = [1, 0, 0, 0] is `loss.backward()` without the kernels autograd spends on slicing the scalar out."""
         ui, het = self.propagate(self.embedding_table)   # [users | items] tables: target-graph sums, behaviour sums
         dp = self.diffusion_process
         n = ui.shape[0]
@@ -240,8 +246,7 @@ class HGDM(nn.Module):
         for dn in (self.usr_denoiser, self.item_denoiser):
             weights += [dn.emb_layer.weight, dn.emb_layer.bias, dn.in_layers[0].weight, dn.in_layers[0].bias,
                         dn.out_layers[0].weight, dn.out_layers[0].bias]
-        res = _RecLossFn.apply(ui, het, noise, ts, ancs, poss, negs, self, validate, *weights)
-        return res[0], res[1], res[2], res[3]
+        return _RecLossFn.apply(ui, het, noise, ts, ancs, poss, negs, self, validate, *weights)
 
     def predict(self):  # Model.py:112-118
         usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = self.forward()

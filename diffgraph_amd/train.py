@@ -21,6 +21,16 @@ from .model_rec import DEFAULT_ARGS, HGDM
 from .optim import Adam
 
 
+def training_step(model, opt, ancs, poss, negs, seed: torch.Tensor) -> torch.Tensor:
+    """One step of Coach.trainEpoch's loop (main.py:120-128): cal_loss, backward, Adam.  `seed` is the float64 device
+    vector [1, 0, 0, 0] = d loss / d (loss, bprLoss, regLoss, diff_loss).  Returns those four values (float64[4])."""
+    res = model.cal_loss_vector(ancs, poss, negs)
+    opt.zero_grad(set_to_none=True)
+    res.backward(seed)                                           # = loss.backward()
+    opt.step()
+    return res
+
+
 class Coach:
     def __init__(self, handler, args=None, device="cuda", use_graph: bool = True, seed: int = 0):
         self.handler, self.args, self.device = handler, args or DEFAULT_ARGS, torch.device(device)
@@ -36,18 +46,17 @@ class Coach:
     def prepareModel(self) -> None:
         self.model = HGDM(self.handler, self.args, device=self.device).eval()   # dropout off: see HGDM.cal_loss
         self.opt = Adam(self.model, lr=self.args.lr, weight_decay=0)
-        self._sums = torch.zeros(3, dtype=torch.float64, device=self.device)        # Loss, recLoss, diffLoss
-        n = len(self.handler.trn_data)
-        self._epoch = torch.zeros((3, n), dtype=torch.int64, device=self.device)     # the epoch's shuffled triples
+        self._sums = torch.zeros(4, dtype=torch.float64, device=self.device)        # Loss, recLoss, regLoss, diffLoss
+        self._seed = torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=self.device)   # d loss / d (the four)
+        n, B = len(self.handler.trn_data), self.args.batch
+        self._n_batches = -(-n // B)
+        # the epoch's shuffled triples, one row of B per batch (the last one padded)
+        self._epoch = torch.zeros((self._n_batches, 3, B), dtype=torch.int64, device=self.device)
         self._batch_no = torch.zeros(1, dtype=torch.int64, device=self.device)       # advanced by every recorded step
-        self._graphs = {}     # batch size -> (recorded step, positions of the batch's pairs inside a batch)
+        self._graphs = {}     # batch size -> recorded step
 
     def _step(self, ancs, poss, negs) -> None:
-        loss, bprLoss, regLoss, diff_loss = self.model.cal_loss(ancs, poss, negs)
-        self.opt.zero_grad(set_to_none=True)
-        loss.backward()
-        self.opt.step()
-        self._sums += torch.stack([loss.detach(), bprLoss.detach(), diff_loss.detach()]).double()
+        self._sums += training_step(self.model, self.opt, ancs, poss, negs, self._seed).detach()
 
     def _snapshot(self):
         o = self.opt
@@ -72,12 +81,10 @@ class Coach:
         epoch's table at the position a device-side batch counter names, and advances the counter: an epoch is then
         replay after replay with nothing in between.  The warm-up steps torch asks for before a capture are real
         steps; their effect on the model, the optimizer, the counter and the loss sums is undone afterwards."""
-        inside = torch.arange(size, dtype=torch.int64, device=self.device)
-
         def step():
-            tri = self._epoch.index_select(1, inside + self._batch_no * self.args.batch)
+            tri = self._epoch.index_select(0, self._batch_no)[0]      # [3, B]: the batch the counter names
             self._batch_no.add_(1)
-            self._step(tri[0], tri[1], tri[2])
+            self._step(tri[0, :size], tri[1, :size], tri[2, :size])
         keep = self._snapshot()
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -91,8 +98,8 @@ class Coach:
         with torch.cuda.graph(graph):
             step()
         self._restore(keep)
-        self._graphs[size] = (graph, inside)
-        return graph, inside
+        self._graphs[size] = graph
+        return graph
 
     # ------------------------------------------------------------------ main.py:107-136
     def trainEpoch(self) -> Dict[str, float]:
@@ -104,10 +111,12 @@ class Coach:
         epoch = torch.stack([trn.rows_dev[order].long(), trn.cols_dev[order].long(), trn.negs_dev[order].long()])
         self._sums.zero_()
         if self.use_graph:          # two recordings at most: the full batch and the epoch's short last one
-            self._epoch.copy_(epoch)
+            flat = self._epoch.permute(1, 0, 2).reshape(3, -1)       # (a copy: the padded table as [3, n_batches * B])
+            flat[:, :n] = epoch
+            self._epoch.copy_(flat.view(3, self._n_batches, B).permute(1, 0, 2))
             for b in range(0, n, B):
                 size = min(B, n - b)
-                graph, _ = self._graphs.get(size) or self._capture(size)
+                graph = self._graphs.get(size) or self._capture(size)
                 if b == 0:
                     self._batch_no.zero_()
                 graph.replay()
@@ -117,7 +126,7 @@ class Coach:
                 self._step(part[0], part[1], part[2])
         ep = self._sums.cpu().tolist()                                             # the epoch's one read-back
         div = max(steps, 1)
-        return {"Loss": ep[0] / div, "recLoss": ep[1] / div, "diffLoss": ep[2] / div}
+        return {"Loss": ep[0] / div, "recLoss": ep[1] / div, "diffLoss": ep[3] / div}
 
     # ------------------------------------------------------------------ main.py:138-167
     def testEpoch(self) -> Dict[str, float]:

@@ -1,0 +1,38 @@
+"""bench.py's contract on a tiny workload: one JSON line with the agreed keys, the roofline and the CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_training_step_line_on_the_tiny_workload():
+    r = _run("--workload", "tiny", "--steps", "3", "--warmup", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 2 and r["unit"] == "edges/s" and r["value"] > 0
+    assert r["vs_baseline"] is None and r["dtype"] == "f32" and "workload" in r["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r["roofline"], k
+    assert r["roofline"]["bound"] == "hbm" and abs(r["roofline"]["frac"] - r["roofline"]["achieved"] / r["roofline"]["peak"]) < 1e-12
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in r["cpu_baseline"], k
+    assert r["cpu_baseline"]["kind"] == "port" and r["config"]["loss"] == r["config"]["loss"]   # a number, not NaN
+
+
+def test_eager_step_gives_the_same_kind_of_line():
+    r = _run("--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline")
+    assert r["config"]["launch"] == "eager" and "cpu_baseline" not in r and r["value"] > 0
