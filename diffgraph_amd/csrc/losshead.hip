@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256) void head_bwd_entries_kernel(const float *ui, 
                                                                const int64_t *negs, int n_batch, int n_user, int n_rows,
                                                                double batch_div, double reg_coef, const float *entries_f,
                                                                const double *g, float *scratch, int *tag, int *cnt,
-                                                               int *slots) {
+                                                               int *slots, int *heavy) {
   const int b = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  if (blockIdx.x == 0 && threadIdx.x == 0) heavy[0] = 0;  // the list head_scatter_kernel fills starts empty
   if (b >= n_batch) return;
   const int64_t a = ancs[b], p = poss[b], n = negs[b];
   const head_rows r = load_rows(ui, out_u, out_i, a, p, n, n_user, l);
@@ -274,9 +275,8 @@ extern "C" int dg_rec_head_bwd(const float *ui, const float *out_u, const float 
   int *tag = row_tags, *cnt = row_tags + n_rows, *slots = row_tags + 2 * (size_t)n_rows;
   // rows named more than kSlots times: a counter and a list behind the int32 copy of the index lists
   int *heavy = reinterpret_cast<int *>(scratch + (size_t)3 * n_batch * (DG_D + 1));
-  DG_HIP(hipMemsetAsync(heavy, 0, sizeof(int), (hipStream_t)stream));
   hipLaunchKernelGGL(head_bwd_entries_kernel, dim3((n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ui, out_u, out_i,
-                     ancs, poss, negs, n_batch, n_user, n_rows, batch_div, reg_coef, entries_f, g, scratch, tag, cnt, slots);
+                     ancs, poss, negs, n_batch, n_user, n_rows, batch_div, reg_coef, entries_f, g, scratch, tag, cnt, slots, heavy);
   hipLaunchKernelGGL(head_scatter_kernel, dim3((3 * n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, n_batch, n_user, g,
                      scratch, tag, cnt, slots, heavy, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
   static bool attr_set = false;  // more than 64 KiB of dynamic LDS has to be opted into once
