@@ -293,6 +293,8 @@ class ShardedRecPropagation:
             tail = [wait, fin]
             prev = outs
         steps += tail
+        steps.insert(0, lambda: self.hook and self.hook("begin"))     # (timing hook round the layers, not the final sum)
+        steps.append(lambda: self.hook and self.hook("end"))
         if G > 2:
             het = be.empty(self.n)
             steps.append(be.prepare_sum(sums[1:], het))
@@ -311,12 +313,8 @@ class ShardedRecPropagation:
             prog = self._program(e0)
             if self.reuse_buffers:
                 self._programs = {key: prog + (e0,)}    # one table at a time; e0 is kept so its address stays taken
-        if self.hook:
-            self.hook("begin")
         for step in prog[0]:
             step()
-        if self.hook:
-            self.hook("end")
         return prog[1]
 
 
@@ -379,7 +377,7 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
     torch.cuda.synchronize()
     hook.enabled = False
     L = prop.n_layers
-    # row blocks: one event pair per layer; user-row shards: one pair per forward pass (its layers interleave)
+    # row blocks: one event pair per layer; user-row shards: one pair round the layers of a forward pass (they interleave)
     layer_ms = float(np.mean([events[k].elapsed_time(events[k + 1]) for k in range(0, len(events), 2)]))
     if not row_blocks:
         layer_ms /= L

@@ -3,11 +3,13 @@
 # passes whose summaries are committed under profiles/.  Usage: tools/collect_profiles.sh TAG   (e.g. r01)
 set -e -o pipefail
 TAG=${1:-r01}
+LEGS=${2:-all}     # "all", or "rest": everything but the Tmall training-step legs (bench line, kernel stats, traffic passes)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # traffic passes first: the bench lines below read the JSON they produce
+if [ "$LEGS" = all ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_tmall_$c -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_tmall_$c.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_industry_$c -o p -- python $R/bench.py --workload industry --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_industry_$c.log 2>&1
@@ -15,8 +17,10 @@ done
 python $R/tools/make_traffic_json.py $O/traffic.json tmall $O/pmc_tmall_FETCH_SIZE $O/pmc_tmall_WRITE_SIZE industry $O/pmc_industry_FETCH_SIZE $O/pmc_industry_WRITE_SIZE > /dev/null
 cp $O/traffic.json $R/profiles/${TAG}_traffic.json
 timeout -k 10 300 python $R/bench.py --steps 50 --warmup 10 > $O/tmall_bench.json 2> $O/tmall_bench.err
-timeout -k 10 300 python $R/bench.py --workload industry --steps 20 --warmup 5 > $O/industry_bench.json 2> $O/industry_bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_tmall -o p -- python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/ks_tmall.log 2>&1
+cp $O/ks_tmall/p_kernel_stats.csv $O/tmall_train_step_kernel_stats.csv
+fi
+timeout -k 10 300 python $R/bench.py --workload industry --steps 20 --warmup 5 > $O/industry_bench.json 2> $O/industry_bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_industry -o p -- python $R/bench.py --workload industry --steps 20 --warmup 5 --no-cpu-baseline > $O/ks_industry.log 2>&1
 # SQ / TA / L2 counters of the layer kernel (forward propagation only, tools/layer_bench.py)
 i=0
@@ -33,6 +37,7 @@ for w in eval_tmall eval_ijcai negsample_tmall metapath_dblp predict_ijcai nc_db
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_eval -o p -- python $R/bench.py --workload eval_tmall --steps 10 --warmup 3 --no-cpu-baseline > $O/ks_eval.log 2>&1
 cp $O/ks_eval/p_kernel_stats.csv $O/eval_tmall_kernel_stats.csv
-cp $O/ks_tmall/p_kernel_stats.csv $O/tmall_train_step_kernel_stats.csv
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_epoch -o p -- python $R/bench.py --workload epoch_tmall --steps 5 --warmup 2 --no-cpu-baseline > $O/ks_epoch.log 2>&1
+cp $O/ks_epoch/p_kernel_stats.csv $O/epoch_tmall_kernel_stats.csv
 cp $O/ks_industry/p_kernel_stats.csv $O/industry_1gpu_kernel_stats.csv
 echo done
