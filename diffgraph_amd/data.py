@@ -73,10 +73,13 @@ _REC_SHAPES: Dict[str, tuple] = {
               "synthetic graph with Tmall's shape; buy/cart/fav link counts as shipped, pv synthesised"),
     "ijcai": (22438, 35573, 199654, [("click", 440265, 5), ("fav", 158119, 41), ("cart", 1330, 42)],
               "synthetic graph with the shipped IJCAI shape (22 438 x 35 573); click synthesised"),
+    "ijcai_readme": (17435, 35920, 198243, [("click", 439652, 6), ("fav", 159874, 43), ("cart", 1599, 44)],
+                     "synthetic graph with the IJCAI shape the README states (17 435 x 35 920, 799 368 links split "
+                     "24.8 / 55 / 20 / 0.2 % over buy / click / fav / cart, the shipped matrices' proportions)"),
     "industry": (1000000, 361, 11945223, [("rel1", 7167133, 11), ("rel2", 4778089, 12)],
                  "synthetic Industry-shaped graph (1M x 361, 23 890 445 links over 3 relations)"),
 }
-_TARGET_SEED = {"tiny": 100, "retail_rocket": 20, "tmall": 30, "ijcai": 40, "industry": 10}
+_TARGET_SEED = {"tiny": 100, "retail_rocket": 20, "tmall": 30, "ijcai": 40, "ijcai_readme": 45, "industry": 10}
 
 
 def rec_workload(name: str) -> RecWorkload:

@@ -1,7 +1,7 @@
 """One fused propagation layer (all graphs of the configuration in one launch) for every configuration of the
 benchmark: HIP events round each layer launch, 20 warm-up + 100 timed forward passes, median and p10 / p90 per layer,
 directed edges/s and algorithmic GB/s (4 nnz + 1032 N bytes per graph-layer) against the 8 TB/s HBM peak.
-Usage: python tools/config_table.py out.json [config ...]     (retail_rocket tmall ijcai dblp industry)"""
+Usage: python tools/config_table.py out.json [config ...]     (retail_rocket tmall ijcai ijcai_readme dblp industry)"""
 import json
 import os
 import sys
@@ -77,7 +77,7 @@ def measure(name):
 
 def main():
     out = sys.argv[1]
-    names = sys.argv[2:] or ["retail_rocket", "tmall", "ijcai", "dblp", "industry"]
+    names = sys.argv[2:] or ["retail_rocket", "tmall", "ijcai", "ijcai_readme", "dblp", "industry"]
     res = []
     for nm in names:
         r = measure(nm)
