@@ -146,7 +146,7 @@ def main():
     workload = args.workload or "tmall"
     if workload.startswith(("eval_", "negsample_", "metapath", "predict_", "nc_dblp", "epoch_")):
         # the stages either side of the propagation path (evaluation, sampling, graph construction)
-        from diffgraph_amd import bench_next
+        import bench_next
         if workload.startswith("eval_"):
             res = bench_next.bench_eval(workload[5:], args.steps, args.warmup, not args.no_cpu_baseline)
         elif workload.startswith("epoch_"):

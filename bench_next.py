@@ -9,10 +9,10 @@ import numpy as np
 import scipy.sparse as sp
 import torch
 
-from . import data as dgdata
-from . import evaluate as ev
-from . import metapath as mp
-from .sampling import PairwiseTrnData
+from diffgraph_amd import data as dgdata
+from diffgraph_amd import evaluate as ev
+from diffgraph_amd import metapath as mp
+from diffgraph_amd.sampling import PairwiseTrnData
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X fp32 MFMA / vector peak
 HBM_PEAK_GBS = 8000.0
@@ -39,7 +39,6 @@ def _coo(u, i, nu, ni):
 def bench_eval(workload: str, steps: int, warmup: int, cpu_baseline: bool):
     """Top-20 of every user against every item with the target behaviour's training pairs masked
     (Coach.testEpoch, DiffGraph-Rec/main.py:153-160)."""
-    from oracle import ref_cpu as O  # checker / CPU baseline only
     wl = dgdata.rec_workload(workload)
     nu, ni, k = wl.n_user, wl.n_item, 20
     usr = (torch.from_numpy(dgdata.xavier_uniform(nu, 64, seed=0)) * 3)
@@ -60,6 +59,7 @@ def bench_eval(workload: str, steps: int, warmup: int, cpu_baseline: bool):
                         "unit": "TFLOP/s", "frac": flop / (dev_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
                         "kernel": "score_topk_kernel + merge_topk_kernel", "flop_per_launch": flop, "ms_per_launch": dev_ms}}
     if cpu_baseline:
+        from oracle import ref_cpu as O      # the CPU baseline leg: the only use of the oracle here
         n_s = 2048
         users = torch.from_numpy(data.test_users[:n_s]).long()
         mask = np.zeros((n_s, ni), np.float32)
@@ -80,7 +80,6 @@ def bench_eval(workload: str, steps: int, warmup: int, cpu_baseline: bool):
 
 def bench_negsample(workload: str, steps: int, warmup: int, cpu_baseline: bool):
     """One negative per training pair of the target behaviour (PairwiseTrnData.negSampling, DataHandler.py:282-289)."""
-    from oracle import ref_cpu as O
     wl = dgdata.rec_workload(workload)
     u, i = wl.target
     ds = PairwiseTrnData(_coo(u, i, wl.n_user, wl.n_item), seed=1)
@@ -99,6 +98,7 @@ def bench_negsample(workload: str, steps: int, warmup: int, cpu_baseline: bool):
                         "bytes_per_launch": alg_bytes, "ms_per_launch": dev_ms,
                         "note": "a launch-latency-sized kernel: 1e5-1e6 pairs of a few dependent 4-byte probes each"}}
     if cpu_baseline:
+        from oracle import ref_cpu as O      # the CPU baseline leg: the only use of the oracle here
         n_s = min(n, 100000)
         t0 = time.perf_counter()
         O.neg_sampling(u[:n_s], i[:n_s], wl.n_item, np.random.default_rng(0))
@@ -144,6 +144,7 @@ def bench_metapath(steps: int, warmup: int, cpu_baseline: bool):
                         "kernel": "spgemm_bitmap_kernel + spgemm_expand_kernel (7 products)", "bytes_per_launch": alg_bytes,
                         "ms_per_launch": dev_ms}}
     if cpu_baseline:
+        from oracle import ref_cpu as O      # the CPU baseline leg: the only use of the oracle here
         binz = lambda m: (m != 0).astype(np.float32)
         t0, n = time.perf_counter(), 0
         while time.perf_counter() - t0 < 10.0:
@@ -160,8 +161,7 @@ def bench_predict(workload: str, steps: int, warmup: int, cpu_baseline: bool):
     """HGDM.predict (DiffGraph-Rec/Model.py:112-118): forward propagation + the 200-step reverse diffusion loop
     for every user and item row; the roofline entry is the reverse loop's (fp32 MFMA: 200 x 17 408 FLOP per row)."""
     from types import SimpleNamespace
-    from oracle import ref_cpu as O
-    from . import CSRGraph, rec
+    from diffgraph_amd import CSRGraph, rec
     dev = torch.device("cuda", torch.cuda.current_device())
     wl = dgdata.rec_workload(workload)
     graphs = [CSRGraph.from_bipartite(u, i, wl.n_user, wl.n_item) for (u, i) in [wl.target] + wl.behaviours]
@@ -190,6 +190,7 @@ def bench_predict(workload: str, steps: int, warmup: int, cpu_baseline: bool):
                         "kernel": "denoise_kernel<MODE_PSAMPLE> (both denoisers, one launch)", "flop_per_launch": flop,
                         "ms_per_launch": loop_ms}}
     if cpu_baseline:
+        from oracle import ref_cpu as O      # the CPU baseline leg: the only use of the oracle here
         n_s = 512
         tab = O.DiffusionTables(noise_scale=1e-4, noise_min=1e-4, noise_max=1e-3, steps=dp.steps)
         dn = model.usr_denoiser
@@ -211,16 +212,15 @@ def bench_nc_dblp(steps: int, warmup: int, cpu_baseline: bool):
     """DiffGraph_NC on DBLP (4 057 authors; meta-path graphs APA / APCPA / APTPA composed on the device from the
     committed edge lists): HGDM.get_allembeds = input projection, 3 x 3 propagation layers, reverse loop, classifier."""
     import os
-    from oracle import ref_cpu as O
-    from . import nc
+    from diffgraph_amd import nc
     dev = torch.device("cuda", torch.cuda.current_device())
-    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dblp_graph.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "dblp_graph.npz"))
     NA, NP, NC, NT = (int(v) for v in g["counts"])
     mk = lambda e, shape: sp.coo_matrix((np.ones(len(e), np.float32), (e[:, 0], e[:, 1])), shape=shape).tocsr()
     AP, PC, PT = mk(g["ap"], (NA, NP)), mk(g["pc"], (NP, NC)), mk(g["pt"], (NP, NT))
     D = mp.DevicePattern.from_scipy
     pats = [mp.compose([D(AP), D(AP.T)]), mp.compose([D(AP), D(PC), D(PC.T), D(AP.T)]), mp.compose([D(AP), D(PT), D(PT.T), D(AP.T)])]
-    from .graph import CSRGraph
+    from diffgraph_amd.graph import CSRGraph
     mats = [p.to_scipy() for p in pats]
     adjs = [CSRGraph.from_scipy(m) for m in mats]
     feats = sp.csr_matrix((g["feat_data"], g["feat_indices"], g["feat_indptr"]), shape=tuple(g["feat_shape"]))
@@ -252,6 +252,7 @@ def bench_nc_dblp(steps: int, warmup: int, cpu_baseline: bool):
                         "note": "the 1 MB tables sit in L2: the layers are bound by the L2 gather rate (12 M edges x 256 B per "
                                 "layer), not by HBM"}}
     if cpu_baseline:
+        from oracle import ref_cpu as O      # the CPU baseline leg: the only use of the oracle here
         T = lambda m: tuple(torch.from_numpy(a.astype(np.int64)) for a in (m.tocoo().row, m.tocoo().col))
         adj_t = [T(m) for m in mats]
         w_t, b_t = model.transform_layer.weight.detach().cpu(), model.transform_layer.bias.detach().cpu()
@@ -271,7 +272,7 @@ def bench_epoch(workload: str, steps: int, warmup: int, cpu_baseline: bool):
     reverse loop, all-rank top-20, Recall / NDCG), as the reference tests after every epoch."""
     import diffgraph_amd as dg
     from types import SimpleNamespace
-    from .train import Coach
+    from diffgraph_amd.train import Coach
     wl = dgdata.rec_workload(workload)
     nu, ni = wl.n_user, wl.n_item
     graphs = [dg.CSRGraph.from_bipartite(u, i, nu, ni) for (u, i) in [wl.target] + wl.behaviours]
@@ -342,7 +343,7 @@ def bench_epoch(workload: str, steps: int, warmup: int, cpu_baseline: bool):
                         "traffic": None, "kernel": "gcn_layer_kernel + hub_reduce_kernel (one fused propagation layer, all graphs)",
                         "bytes_per_launch": layer_bytes, "ms_per_launch": layer_ms}}
     if cpu_baseline:
-        from oracle import ref_cpu as O
+        from oracle import ref_cpu as O      # the CPU baseline leg: the only use of the oracle here
         T = torch.from_numpy
         ue, ie = T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))
         mk = lambda ui: tuple(T(a.astype(np.int64)) for a in dgdata.bipartite_edges(ui[0], ui[1], nu))
