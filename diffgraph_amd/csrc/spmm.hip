@@ -592,6 +592,32 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
 
 constexpr int kExchangeCus = 8;  // CUs kept free of lds_rows_kernel workgroups under DG_ROWS_FULL_ONLY
 
+// `total` workgroups shared out in proportion to the weights (largest remainders; every weighted task gets one at least).
+void apportion(int total, const double *w, int n, int32_t *cnt) {
+  double wsum = 0, frac[DG_MAX_TASKS];
+  for (int k = 0; k < n; ++k) wsum += w[k];
+  int used = 0;
+  for (int k = 0; k < n; ++k) {
+    cnt[k] = 0;
+    frac[k] = -1.0;
+    if (w[k] > 0) {
+      const double x = total * w[k] / wsum;
+      cnt[k] = std::max(1, (int)x);
+      frac[k] = x - (int)x;
+      used += cnt[k];
+    }
+  }
+  while (used < total) {
+    int best = -1;
+    for (int k = 0; k < n; ++k)
+      if (frac[k] >= 0 && (best < 0 || frac[k] > frac[best])) best = k;
+    if (best < 0) break;
+    ++cnt[best];
+    frac[best] = -1.0;
+    ++used;
+  }
+}
+
 int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_t stream) {
   const int n_tasks = batch.n_tasks;
   int32_t blocks = 0, hub_blocks = 0;
@@ -634,12 +660,13 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     // A call for the non-partial rows alone runs beside the exchange of the partial sums: lds_rows_kernel holds a whole
     // CU per workgroup until it ends, so a few CUs are left to the collective's kernel.
     const int lds_cus = rows_sel == DG_ROWS_FULL_ONLY ? std::max(1, cus - kExchangeCus) : cus;
+    int32_t share[DG_MAX_TASKS];
+    apportion(lds_cus, w, n_tasks, share);
     for (int k = 0; k < n_tasks; ++k) {
       dg_task_dev &t = batch.t[k];
       t.lds_blk_begin = lds_blocks;
       if (w[k] > 0) {
-        int32_t cnt = std::max(1, (int32_t)(lds_cus * w[k] / wsum));
-        cnt = std::min(cnt, (t.lds_split + 63) / 64);
+        const int32_t cnt = std::min(share[k], (t.lds_split + 63) / 64);
         t.lds_blk_count = cnt;
         lds_blocks += cnt;
         lds_rows_max = std::max(lds_rows_max, t.n - t.lds_split);
@@ -653,13 +680,13 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
       w[k] = batch.t[k].lds_split > 0 ? 0.5 * (double)graphs[k]->nnz + 1500.0 * batch.t[k].n_windows : 0.0;
       wsum += w[k];
     }
+    apportion(cus, w, n_tasks, share);
     for (int k = 0; k < n_tasks; ++k) {
       dg_task_dev &t = batch.t[k];
       t.win_blk_begin = win_blocks;
       t.win_blk_count = 0;
       if (w[k] > 0) {
-        int32_t cnt = std::max(1, (int32_t)std::lround(cus * w[k] / wsum));
-        t.win_blk_count = std::min(std::min(cnt, t.n_windows), DG_WIN_MAX_BLOCKS);
+        t.win_blk_count = std::min(std::min(share[k], t.n_windows), DG_WIN_MAX_BLOCKS);
         win_blocks += t.win_blk_count;
       }
     }
