@@ -329,12 +329,14 @@ def test_denoiser_weight_gradients_two_denoisers_one_call():
         ops.denoiser_wgrad_many(jobs + jobs[:1], T_)
 
 
-@pytest.mark.parametrize("n_batch", [1, 37, 2048, 8192])
-def test_rec_loss_head_matches_torch_autograd(n_batch):
+@pytest.mark.parametrize("n_batch,nu,ni", [(1, 50, 70), (37, 50, 70), (2048, 50, 70), (8192, 50, 70), (8192, 300, 500),
+                                          (2048, 3000, 40)])
+def test_rec_loss_head_matches_torch_autograd(n_batch, nu, ni):
     """The fused loss head (values and all five gradients) against the reference's own formulation in torch
-    ops (DiffGraph-Rec/Model.py:101-111), with batch entries that name the same row many times."""
+    ops (DiffGraph-Rec/Model.py:101-111), with batch entries that name the same row many times: every row more
+    often than the per-row slots hold (50 x 70), more such rows than the heavy-row kernel has workgroups (300 x 500),
+    and a mix of rows named once, a few times and hundreds of times (3000 x 40)."""
     from diffgraph_amd.model_rec import _RecHeadFn, pairPredict
-    nu, ni = 50, 70
     gen = torch.Generator().manual_seed(n_batch)
     mk = lambda *s: torch.randn(*s, generator=gen)
     ui, out_u, out_i = mk(nu + ni, 64) * 0.3, mk(nu, 64) * 0.1, mk(ni, 64) * 0.1
