@@ -106,9 +106,69 @@ def cpu_baseline(wl, budget_s=20.0, passes_per_call=2):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 20:
             break
-    return {"value": edges_per_pass * n / el, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full propagation passes ({2 * (1 + len(wl.behaviours))} SpMM each, index_add_ form) of the {wl.name} workload, "
-                      f"torch {torch.__version__} CPU, {el:.1f} s"}
+    res = {"value": edges_per_pass * n / el, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} full propagation passes ({2 * (1 + len(wl.behaviours))} SpMM each, index_add_ form) of the {wl.name} workload, "
+                     f"torch {torch.__version__} CPU, {el:.1f} s"}
+    res["spmm_variants"] = cpu_spmm_variants(target, wl.n, torch.cat([ue, ie]))
+    # the same propagation over prebuilt CSR A_hat matrices (torch's fastest CPU form on some hosts): the better of
+    # the two is the baseline
+    try:
+        import torch.nn.functional as F
+        mats = [O.normalised_adj_csr(s_, d_, wl.n) for (s_, d_) in [target] + behs]
+        e0 = torch.cat([ue, ie])
+
+        def forward_csr():
+            sums = []
+            for a in mats:
+                e, acc = e0, e0
+                for _ in range(2):
+                    e = F.leaky_relu(a @ e, 0.5)
+                    acc = acc + F.normalize(e, p=2, dim=1)
+                sums.append(acc)
+            return sums[0], sum(sums[1:])
+        forward_csr()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s / 2 and k < 20:
+            forward_csr()
+            k += 1
+        el2 = time.perf_counter() - t0
+        res["index_add_value"], res["csr_value"] = res["value"], edges_per_pass * k / el2
+        if res["csr_value"] > res["value"]:
+            res["value"] = res["csr_value"]
+            res["sample"] = (f"{k} full propagation passes ({2 * (1 + len(wl.behaviours))} SpMM each) of the {wl.name} workload over prebuilt "
+                             f"fp32 CSR A_hat matrices (torch.sparse CSR @ dense; faster here than the index_add_ form, "
+                             f"{res['index_add_value']:.3g} edges/s), torch {torch.__version__} CPU, {el2:.1f} s")
+    except Exception as exc:   # torch builds without CSR kernels keep the index_add_ figure
+        res["csr_value"] = repr(exc)[:200]
+    return res
+
+
+def cpu_spmm_variants(edges, n, x, budget_s=2.0):
+    """The bare SpMM A_hat . X of the target graph on the host cores in the three forms it can take in torch: the
+    fp32 COO A_hat the reference's DataHandler builds (DiffGraph-Rec/DataHandler.py:103-118), the same as CSR, and
+    the index_add_ form of the oracle.  Directed edges per second each (or the error text where torch refuses)."""
+    from oracle import ref_cpu as O
+    src, dst = edges
+    out = {}
+    try:
+        csr = O.normalised_adj_csr(src, dst, n)
+        coo = csr.to_sparse_coo().coalesce()
+        no = torch.pow(O.degrees(src, dst, n)[0].float().clamp(min=1), -0.5).view(-1, 1)
+        forms = {"coo_sparse_mm": lambda: torch.sparse.mm(coo, x), "csr_sparse_mm": lambda: csr @ x,
+                 "index_add": lambda: torch.zeros_like(x).index_add_(0, dst, (x * no)[src])}
+    except Exception as exc:        # a torch build without sparse CPU kernels: say so instead of failing the bench
+        return {"error": repr(exc)[:200]}
+    for name, fn in forms.items():
+        try:
+            fn()
+            t0, k = time.perf_counter(), 0
+            while time.perf_counter() - t0 < budget_s and k < 50:
+                fn()
+                k += 1
+            out[name] = len(src) * k / (time.perf_counter() - t0)
+        except Exception as exc:
+            out[name] = repr(exc)[:200]
+    return out
 
 
 def main():
