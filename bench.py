@@ -204,7 +204,7 @@ def main():
         return
 
     workload = args.workload or "tmall"
-    if workload.startswith(("eval_", "negsample_", "metapath", "predict_", "nc_dblp", "epoch_")):
+    if workload.startswith(("eval_", "negsample_", "metapath", "predict_", "nc_dblp", "nc_train", "epoch_")):
         # the stages either side of the propagation path (evaluation, sampling, graph construction)
         import bench_next
         if workload.startswith("eval_"):
@@ -213,6 +213,8 @@ def main():
             res = bench_next.bench_epoch(workload[6:], args.steps, args.warmup, not args.no_cpu_baseline)
         elif workload.startswith("predict_"):
             res = bench_next.bench_predict(workload[8:], args.steps, args.warmup, not args.no_cpu_baseline)
+        elif workload.startswith("nc_train"):
+            res = bench_next.bench_nc_train(args.steps, args.warmup, not args.no_cpu_baseline)
         elif workload.startswith("nc_dblp"):
             res = bench_next.bench_nc_dblp(args.steps, args.warmup, not args.no_cpu_baseline)
         elif workload.startswith("negsample_"):

@@ -208,11 +208,12 @@ def bench_predict(workload: str, steps: int, warmup: int, cpu_baseline: bool):
     return res
 
 
-def bench_nc_dblp(steps: int, warmup: int, cpu_baseline: bool):
-    """DiffGraph_NC on DBLP (4 057 authors; meta-path graphs APA / APCPA / APTPA composed on the device from the
-    committed edge lists): HGDM.get_allembeds = input projection, 3 x 3 propagation layers, reverse loop, classifier."""
+def _nc_dblp_setup():
+    """DBLP from the committed edge lists: the three author graphs composed on the device, row-normalised author
+    features (DiffGraph_NC/DataHandler.py:147-174, 254-259), a random-init model."""
     import os
     from diffgraph_amd import nc
+    from diffgraph_amd.graph import CSRGraph
     dev = torch.device("cuda", torch.cuda.current_device())
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "dblp_graph.npz"))
     NA, NP, NC, NT = (int(v) for v in g["counts"])
@@ -220,7 +221,6 @@ def bench_nc_dblp(steps: int, warmup: int, cpu_baseline: bool):
     AP, PC, PT = mk(g["ap"], (NA, NP)), mk(g["pc"], (NP, NC)), mk(g["pt"], (NP, NT))
     D = mp.DevicePattern.from_scipy
     pats = [mp.compose([D(AP), D(AP.T)]), mp.compose([D(AP), D(PC), D(PC.T), D(AP.T)]), mp.compose([D(AP), D(PT), D(PT.T), D(AP.T)])]
-    from diffgraph_amd.graph import CSRGraph
     mats = [p.to_scipy() for p in pats]
     adjs = [CSRGraph.from_scipy(m) for m in mats]
     feats = sp.csr_matrix((g["feat_data"], g["feat_indices"], g["feat_indptr"]), shape=tuple(g["feat_shape"]))
@@ -231,6 +231,68 @@ def bench_nc_dblp(steps: int, warmup: int, cpu_baseline: bool):
     features = torch.from_numpy(np.asarray(sp.diags(r_inv).dot(feats).todense(), dtype=np.float32))
     torch.manual_seed(5)
     model = nc.HGDM(features.shape[1]).eval()
+    return dev, NA, mats, adjs, features, model, torch.from_numpy(np.asarray(g["labels"])).long()
+
+
+def bench_nc_train(steps: int, warmup: int, cpu_baseline: bool):
+    """One training step of DiffGraph_NC on DBLP (DiffGraph_NC/main.py:372-386): cal_loss over a batch of 8 labelled
+    authors (3 x 3 propagation layers, q_sample + denoiser + SNR loss, classifier, NLL), backward, Adam."""
+    dev, NA, mats, adjs, features, model, labels = _nc_dblp_setup()
+    fd = features.to(dev)
+    onehot = torch.zeros(NA, 4, device=dev)
+    onehot[torch.arange(NA, device=dev), labels.to(dev)] = 1.0
+    gen = torch.Generator().manual_seed(1)
+    ancs = torch.sort(torch.randperm(NA, generator=gen)[: model.args.batch])[0].to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3, weight_decay=0)
+
+    def step():
+        nll, diff = model.cal_loss(ancs, onehot, adjs, fd)
+        opt.zero_grad(set_to_none=True)
+        (nll + diff).backward()
+        opt.step()
+        return nll, diff
+    wall_ms, dev_ms = _timed(step, steps, warmup)
+    nll, diff = step()
+    with torch.no_grad():
+        embed = model.transform_layer(fd)
+        _, prop_ms = _timed(lambda: model.propagate(adjs, embed), max(steps, 10), 3)
+    nnz = [m.nnz for m in mats]
+    L = model.args.gcn_layer
+    layer_bytes = sum(4 * e + 1032 * NA for e in nnz)
+    res = {"metric": "DiffGraph_NC training step: SpMM edges/sec through cal_loss + backward + Adam", "value": 2 * L * sum(nnz) / (wall_ms * 1e-3),
+           "unit": "edges/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": wall_ms, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "DBLP edge lists and author features (tests/golden/dblp_graph.npz), random-init weights",
+           "config": {"workload": "nc_train_dblp: APA / APCPA / APTPA author graphs, batch of 8 authors", "authors": NA,
+                      "directed_edges_per_graph": nnz, "layers": L, "device_ms_per_step": dev_ms,
+                      "loss": [float(nll.detach()), float(diff.detach())], "launch": "eager"},
+           "roofline": {"bound": "hbm", "achieved": L * layer_bytes / (prop_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": L * layer_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "gcn_layer_kernel + hub_reduce_kernel, forward propagation: 3 layers x 3 graphs",
+                        "bytes_per_launch": layer_bytes, "ms_per_launch": prop_ms / L,
+                        "note": "the 1 MB tables sit in L2: the layers are bound by the L2 gather rate, not by HBM"}}
+    if cpu_baseline:
+        from oracle import ref_cpu as O      # the CPU baseline leg: the only use of the oracle here
+        T = lambda m: tuple(torch.from_numpy(a.astype(np.int64)) for a in (m.tocoo().row, m.tocoo().col))
+        adj_t = [T(m) for m in mats]
+        w_t = model.transform_layer.weight.detach().cpu().clone().requires_grad_(True)
+        b_t = model.transform_layer.bias.detach().cpu().clone().requires_grad_(True)
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 10.0 and k < 10:
+            outs = O.nc_forward(adj_t, features, w_t, b_t, L)
+            sum(o.sum() for o in outs).backward()
+            k += 1
+        el = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": k * 2 * L * sum(nnz) / el, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{k} x forward + autograd backward of the propagation (projection + {L} layers x 3 graphs, "
+                                         f"index_add_ form), {el:.1f} s"}
+    return res
+
+
+def bench_nc_dblp(steps: int, warmup: int, cpu_baseline: bool):
+    """DiffGraph_NC on DBLP (4 057 authors; meta-path graphs APA / APCPA / APTPA composed on the device from the
+    committed edge lists): HGDM.get_allembeds = input projection, 3 x 3 propagation layers, reverse loop, classifier."""
+    dev, NA, mats, adjs, features, model, _ = _nc_dblp_setup()
     fd = features.to(dev)
     with torch.no_grad():
         wall_ms, _ = _timed(lambda: model.get_allembeds(adjs, fd), steps, warmup)

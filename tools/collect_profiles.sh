@@ -32,7 +32,7 @@ for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST
   python $R/tools/pmc_summary.py $O/pmc_layer_$i gcn_layer >> $O/pmc_gcn_layer.txt
   python $R/tools/pmc_summary.py $O/pmc_layer_$i hub_reduce >> $O/pmc_gcn_layer.txt
 done
-for w in eval_tmall eval_ijcai negsample_tmall metapath_dblp predict_ijcai nc_dblp epoch_tmall; do
+for w in eval_tmall eval_ijcai negsample_tmall metapath_dblp predict_ijcai nc_dblp nc_train_dblp epoch_tmall; do
   timeout -k 10 200 python $R/bench.py --workload $w --steps 10 --warmup 3 > $O/${w}_bench.json 2> $O/${w}_bench.err
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_eval -o p -- python $R/bench.py --workload eval_tmall --steps 10 --warmup 3 --no-cpu-baseline > $O/ks_eval.log 2>&1
