@@ -52,6 +52,7 @@ class Coach:
         self._n_batches = -(-n // B)
         # the epoch's shuffled triples, one row of B per batch (the last one padded)
         self._epoch = torch.zeros((self._n_batches, 3, B), dtype=torch.int64, device=self.device)
+        self._flat = torch.zeros((3, self._n_batches * B), dtype=torch.int64, device=self.device)
         self._batch_no = torch.zeros(1, dtype=torch.int64, device=self.device)       # advanced by every recorded step
         self._graphs = {}     # batch size -> recorded step
 
@@ -111,9 +112,8 @@ class Coach:
         epoch = torch.stack([trn.rows_dev[order].long(), trn.cols_dev[order].long(), trn.negs_dev[order].long()])
         self._sums.zero_()
         if self.use_graph:          # two recordings at most: the full batch and the epoch's short last one
-            flat = self._epoch.permute(1, 0, 2).reshape(3, -1)       # (a copy: the padded table as [3, n_batches * B])
-            flat[:, :n] = epoch
-            self._epoch.copy_(flat.view(3, self._n_batches, B).permute(1, 0, 2))
+            self._flat[:, :n] = epoch                                 # [3, n_batches * B]; the padding stays zero
+            self._epoch.copy_(self._flat.view(3, self._n_batches, B).permute(1, 0, 2))
             for b in range(0, n, B):
                 size = min(B, n - b)
                 graph = self._graphs.get(size) or self._capture(size)

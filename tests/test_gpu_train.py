@@ -112,3 +112,22 @@ def test_run_tests_every_epoch_and_checkpoints(tmp_path):
     d = Coach(_handler(), args, device=DEV, seed=1)
     d.loadModel(path)
     assert d.testEpoch()["Recall"] == pytest.approx(out["Recall"], abs=1e-12)
+
+
+@pytest.mark.parametrize("batch", [62, 256])
+def test_batch_sizes_that_divide_the_data_or_exceed_it(batch):
+    """186 training pairs: batch 62 leaves no short last batch, batch 256 leaves only one (len // batch == 0: the
+    reference would divide by zero there; Coach divides by 1).  Replayed and eager epochs see the same batches."""
+    args = _args(batch)
+    res = {}
+    for use_graph in (True, False):
+        torch.manual_seed(4)
+        c = Coach(_handler(), args, device=DEV, use_graph=use_graph, seed=2)
+        c.prepareModel()
+        before = c.model.embedding_table.detach().clone()
+        res[use_graph] = [c.trainEpoch() for _ in range(2)]
+        assert not torch.equal(before, c.model.embedding_table)
+        if use_graph:
+            assert sorted(c._graphs) == [min(batch, 186)]
+    for a, b in zip(res[True], res[False]):
+        assert np.isfinite(a["Loss"]) and a["Loss"] == pytest.approx(b["Loss"], rel=0.2)
