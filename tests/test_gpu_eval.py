@@ -47,7 +47,10 @@ def test_eval_golden_reference_test_epoch():
 
 
 @pytest.mark.parametrize("nu,ni,k,n_trn", [(1, 5, 3, 2), (130, 33, 20, 1500), (257, 1000, 1, 0), (500, 4099, 32, 60000),
-                                            (64, 40, 20, 2200)])
+                                            (64, 40, 20, 2200),
+                                            # every list size the kernel is built for (k rounded up to 4, 8, ..., 32)
+                                            (300, 2000, 5, 9000), (300, 2000, 9, 9000), (300, 2000, 13, 9000),
+                                            (300, 2000, 24, 9000), (300, 2000, 25, 9000), (300, 2000, 29, 9000)])
 def test_eval_ragged_sizes_against_oracle(nu, ni, k, n_trn):
     """Ragged user / item counts, k = 1 and 32, no training data, and users whose training row leaves
     fewer than k items (the masked ones then fill the list at -1e8, lowest item id first)."""
@@ -225,3 +228,38 @@ def test_spgemm_pattern_ragged_against_scipy():
         np.testing.assert_array_equal(got.indices, want.indices)
     with pytest.raises(dg.DiffGraphHipError):
         mp.spgemm_pattern(mp.DevicePattern.from_scipy(sp.eye(4, format="csr")), mp.DevicePattern.from_scipy(sp.eye(4, 300000, format="csr")))
+
+
+@pytest.mark.parametrize("k", [1, 7, 20])
+def test_eval_exact_ties_go_to_the_lower_item_id(k):
+    """Item tables with a handful of distinct rows repeated hundreds of times: most scores of a user tie EXACTLY.
+    The kernel's lists must then be the stable order -- by falling score, equal scores by rising item id -- across
+    tile, half-wavefront and item-range boundaries."""
+    nu, ni = 200, 3000
+    gen = torch.Generator().manual_seed(k)
+    usr = torch.randn(nu, 64, generator=gen)
+    base = torch.randn(9, 64, generator=gen)
+    itm = base[torch.randint(0, 9, (ni,), generator=gen)]
+    trn_u, trn_i = dgdata.synth_interactions(nu, ni, 5000, 8)
+    tst_u, tst_i = np.arange(nu, dtype=np.int32), np.zeros(nu, np.int32)
+    data = ev.AllRankTestData(coo(tst_u, tst_i, nu, ni), coo(trn_u, trn_i, nu, ni))
+    vals, top = ev.all_rank_topk(usr.to(DEV), itm.to(DEV), data.test_users_dev, data, k)
+    # the kernel's own fp32 scores decide what ties: recompute them on the device, item by distinct row
+    sc = (usr.to(DEV) @ base.to(DEV).t()).cpu().double().numpy()          # [nu, 9] (any rounding is shared by equal rows)
+    which = np.array([int(np.argmin(((base - itm[j]) ** 2).sum(1).numpy())) for j in range(ni)])
+    got = top.cpu().numpy()
+    mask = np.zeros((nu, ni), bool)
+    mask[trn_u, trn_i] = True
+    for r, u in enumerate(data.test_users):
+        items = got[r]
+        assert len(set(items.tolist())) == k and not mask[u, items].any()
+        cls = which[items]
+        # classes appear by falling score, and inside a class the ids ascend and are the class's lowest unmasked ids
+        order = [c for j, c in enumerate(cls) if j == 0 or c != cls[j - 1]]
+        assert len(order) == len(set(order)) and all(sc[u, a] >= sc[u, b] for a, b in zip(order, order[1:]))
+        for c in set(cls.tolist()):
+            mine = items[cls == c]
+            avail = np.nonzero((which == c) & ~mask[u])[0]
+            np.testing.assert_array_equal(mine, avail[: len(mine)])
+            if c != order[-1]:
+                assert len(mine) == len(avail)      # a better class is used up before the next one starts
