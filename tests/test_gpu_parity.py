@@ -853,3 +853,26 @@ def test_industry_size_forward_against_oracle():
     for got, w, nm in zip(fwd, want, ("tu", "ti", "hu", "hi")):
         assert w.dtype == torch.float64
         assert_rows_close(got, w, what="industry forward " + nm)
+
+
+@pytest.mark.parametrize("shape", ["lds", "general"])
+def test_sharded_forward_with_reused_buffers(shape):
+    """reuse_buffers=True: the prepared launches of the first pass are replayed over the same buffers -- the same
+    bits as a fresh pass, also after the table's values change in place and after a table at another address."""
+    from diffgraph_amd.dist import HipBackend, ShardedRecPropagation
+    nu, ni = (9000, 37) if shape == "lds" else (300, 200)
+    inter = [dgdata.synth_interactions(nu, ni, m, seed) for m, seed in ((3 * nu, 1), (8 * nu, 2), (nu, 3))]
+    be = HipBackend(torch.device(DEV))
+    fresh = ShardedRecPropagation(inter, nu, ni, 0, 1, be)
+    kept = ShardedRecPropagation(inter, nu, ni, 0, 1, be, reuse_buffers=True)
+    gen = torch.Generator().manual_seed(1)
+    e0 = dev(torch.randn(nu + ni, 64, generator=gen) * 0.1)
+    for trial in range(3):
+        want = [t.clone() for t in fresh.forward(e0)]
+        got = kept.forward(e0)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), trial
+        if trial == 0:
+            e0.mul_(1.5)                                                  # same address, new values
+        else:
+            e0 = dev(torch.randn(nu + ni, 64, generator=gen) * 0.1)       # another table
+    assert len(kept._programs) == 1
