@@ -93,6 +93,7 @@ SIGNATURES = {
     "dg_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                               C.c_int32, C.c_void_p, C.c_void_p]),
     "dg_time_bias_table": (C.c_int, [C.POINTER(Denoiser), C.c_int32, C.c_void_p, C.c_void_p]),
+    "dg_time_bias_tables": (C.c_int, [C.POINTER(C.POINTER(Denoiser)), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "dg_denoise_fwd": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_int32, C.c_void_p, C.c_void_p]),
     "dg_p_sample_loop": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

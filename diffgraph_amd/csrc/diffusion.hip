@@ -340,7 +340,15 @@ struct tb_args {
 
 // table[t][f] = b_in[f] + sum_e W_in[f][64+e] * (b_emb[e] + sum_k W_emb[e][k] * te_t[k]),
 // te_t = [cos(t*freqs), sin(t*freqs)]  (Model.py:215-220 and the last 8 input columns of :226-227).
-__global__ __launch_bounds__(64) void time_bias_kernel(tb_args a, float *__restrict__ table) {
+constexpr int kMaxBiasTables = 4;
+struct tb_batch {
+  tb_args a[kMaxBiasTables];
+  float *table[kMaxBiasTables];
+};
+
+__global__ __launch_bounds__(64) void time_bias_kernel(const tb_batch all) {
+  const tb_args &a = all.a[blockIdx.y];
+  float *__restrict__ table = all.table[blockIdx.y];
   const int t = blockIdx.x, f = threadIdx.x;
   float te[8];
 #pragma unroll
@@ -385,16 +393,29 @@ int launch_one(dn_task &t, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int dg_time_bias_table(const dg_denoiser *dn, int32_t n_steps, float *table, void *stream) {
-  if (!dn || !dn->w_emb || !dn->b_emb || !dn->w_in || !dn->b_in || !dn->freqs_host || !table)
-    return dg_fail(DG_ERR_ARG, "dg_time_bias_table: NULL argument");
+extern "C" int dg_time_bias_tables(const dg_denoiser *const *dns, float *const *tables, int32_t n_tables, int32_t n_steps,
+                                   void *stream) {
+  if (!dns || !tables || n_tables <= 0 || n_tables > kMaxBiasTables)
+    return dg_fail(DG_ERR_ARG, "dg_time_bias_tables: n_tables must be in [1,%d] (got %d)", kMaxBiasTables, n_tables);
   if (n_steps <= 0) return dg_fail(DG_ERR_ARG, "dg_time_bias_table: n_steps must be positive");
-  tb_args a;
-  a.w_emb = dn->w_emb; a.b_emb = dn->b_emb; a.w_in = dn->w_in; a.b_in = dn->b_in;
-  for (int k = 0; k < 4; ++k) a.freqs[k] = dn->freqs_host[k];
-  hipLaunchKernelGGL(time_bias_kernel, dim3(n_steps), dim3(64), 0, (hipStream_t)stream, a, table);
+  tb_batch b;
+  for (int i = 0; i < n_tables; ++i) {
+    const dg_denoiser *dn = dns[i];
+    if (!dn || !dn->w_emb || !dn->b_emb || !dn->w_in || !dn->b_in || !dn->freqs_host || !tables[i])
+      return dg_fail(DG_ERR_ARG, "dg_time_bias_table: NULL argument");
+    tb_args &a = b.a[i];
+    a.w_emb = dn->w_emb; a.b_emb = dn->b_emb; a.w_in = dn->w_in; a.b_in = dn->b_in;
+    for (int k = 0; k < 4; ++k) a.freqs[k] = dn->freqs_host[k];
+    b.table[i] = tables[i];
+  }
+  for (int i = n_tables; i < kMaxBiasTables; ++i) { b.a[i] = b.a[0]; b.table[i] = b.table[0]; }
+  hipLaunchKernelGGL(time_bias_kernel, dim3(n_steps, n_tables), dim3(64), 0, (hipStream_t)stream, b);
   DG_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int dg_time_bias_table(const dg_denoiser *dn, int32_t n_steps, float *table, void *stream) {
+  return dg_time_bias_tables(&dn, &table, 1, n_steps, stream);
 }
 
 extern "C" int dg_q_sample(const float *x0, const float *noise, const int64_t *t, const float *sqrt_ac,

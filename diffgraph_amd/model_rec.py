@@ -113,9 +113,8 @@ class _RecLossFn(torch.autograd.Function):
         ui, het = ui.contiguous(), het.contiguous()
         spans = []
         for dn, begin, n in ((model.usr_denoiser, 0, nu), (model.item_denoiser, nu, model.n_item)):
-            p = dn.params(bool(dn.norm))
-            p.time_bias(gd.steps, refresh=True)
-            spans.append(ops.LossSpan(p, begin, n))
+            spans.append(ops.LossSpan(dn.params(bool(dn.norm)), begin, n))
+        ops.refresh_time_bias([sp.dn for sp in spans], gd.steps)      # both denoisers' tables, one launch
         sa = gd._dev("sqrt_alphas_cumprod", dev) if gd.noise_scale != 0 else None
         sb = gd._dev("sqrt_one_minus_alphas_cumprod", dev) if gd.noise_scale != 0 else None
         lw = gd._dev("loss_weight", dev, torch.float64)

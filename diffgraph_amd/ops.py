@@ -248,6 +248,18 @@ class DenoiserParams:
         return self._tb
 
 
+def refresh_time_bias(params: Sequence["DenoiserParams"], n_steps: int) -> None:
+    """DenoiserParams.time_bias(n_steps, refresh=True) for several denoisers (at most four) in one launch."""
+    dev = params[0].device
+    tabs = [torch.empty((n_steps, DG_D), dtype=torch.float32, device=dev) for _ in params]
+    dns = (C.POINTER(_lib.Denoiser) * len(params))(*[C.pointer(p.c) for p in params])
+    ptrs = (C.c_void_p * len(params))(*[t.data_ptr() for t in tabs])
+    rc = _lib.load().dg_time_bias_tables(dns, ptrs, len(params), n_steps, _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_time_bias_tables")
+    for p, t in zip(params, tabs):
+        p._tb, p._tb_steps = t, n_steps
+
+
 def _check_t(t: torch.Tensor, n: int, n_steps: int, validate: bool) -> torch.Tensor:
     _vec(t, "timesteps", torch.int64, n)
     if validate and n > 0:

@@ -223,6 +223,9 @@ typedef struct dg_denoiser {
  * b_in + W_in[:,64:72] . emb_layer([cos(t f), sin(t f)])  (Model.py:215-220,225-227).
  * dg_time_bias_table fills it (device pointer, n_steps*64 floats). */
 int dg_time_bias_table(const dg_denoiser *dn, int32_t n_steps, float *table, void *stream);
+/* The tables of up to four denoisers (a training step's usr_denoiser and item_denoiser) in one launch. */
+int dg_time_bias_tables(const dg_denoiser *const *dns, float *const *tables, int32_t n_tables,
+                        int32_t n_steps, void *stream);
 
 /* a7: Denoise.forward(x, timesteps, mess_dropout=False) (DiffGraph-Rec/Model.py:214-234),
  * eval-mode arithmetic.  x,out: [n][64]; t: int64[n] in [0,n_steps); table from above. */
