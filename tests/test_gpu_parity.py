@@ -876,3 +876,81 @@ def test_sharded_forward_with_reused_buffers(shape):
         else:
             e0 = dev(torch.randn(nu + ni, 64, generator=gen) * 0.1)       # another table
     assert len(kept._programs) == 1
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_layer_random_graphs_and_schedules(seed):
+    """A seeded sweep over graph shapes (directed and bipartite-symmetric, uniform and power-law degrees, repeated
+    edges, isolated nodes, one side small enough for the LDS path) and schedule knobs: the single layer, forward and
+    transposed, and the fused two-layer propagation against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ("directed", "bipartite", "powerlaw", "small_side")[seed % 4]
+    if kind == "directed":
+        n = int(rng.integers(2, 3000))
+        m = int(rng.integers(1, 40 * n))
+        src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+    elif kind == "powerlaw":
+        n = int(rng.integers(50, 4000))
+        m = int(rng.integers(n, 60 * n))
+        w = 1.0 / np.arange(1, n + 1) ** rng.uniform(0.6, 1.4)
+        src, dst = rng.integers(0, n, m), rng.choice(n, m, p=w / w.sum())
+        src, dst = np.concatenate([src, dst]), np.concatenate([dst, src])        # symmetric, with repeated edges
+    else:
+        nu = int(rng.integers(30, 3000)) if kind == "bipartite" else int(rng.integers(6000, 12000))
+        ni = int(rng.integers(30, 3000)) if kind == "bipartite" else int(rng.integers(1, 90))
+        m = int(rng.integers(1, min(nu * ni, 30 * (nu + ni))))
+        key = np.unique(rng.integers(0, nu, m).astype(np.int64) * ni + rng.integers(0, ni, m))
+        u, i = (key // ni).astype(np.int32), (key % ni).astype(np.int32)
+        n = nu + ni
+        src, dst = dgdata.bipartite_edges(u, i, nu)
+    src, dst = src.astype(np.int32), dst.astype(np.int32)
+    knobs = dict(group_max=int(rng.choice([0, 2, 8, 64])), seg_len=int(rng.choice([0, 64, 256])))
+    g = dg.CSRGraph(src, dst, n, **knobs)
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(seed))
+    s, d = T(src.astype(np.int64)), T(dst.astype(np.int64))
+    what = f"seed {seed} {kind} n={n} edges={len(src)} {knobs} {g.schedule()}"
+    assert_rows_close(ops.spmm_norm_act(g, dev(x), 0.5), O.gcn_layer(s, d, n, x, slope=0.5), what=what)
+    assert_rows_close(ops.spmm_norm_act(g, dev(x), 1.0, transpose=True), O.gcn_layer(d, s, n, x, slope=None), what=what + " T")
+    # two fused layers with the running sum, as HGDM.forward chains them (raw activation feeds the next layer)
+    e0 = dev(x * 0.1)
+    acc, e1 = torch.empty_like(e0), torch.empty_like(e0)
+    from diffgraph_amd._lib import DG_ACC_REBUILD, DG_IN_PRESCALED, DG_OUT_PRESCALE
+    ops.gcn_layer_batched([ops.LayerTask(g, e0, e1, None, None, DG_OUT_PRESCALE, 0.5)])
+    ops.gcn_layer_batched([ops.LayerTask(g, e1, None, e0, acc, DG_IN_PRESCALED | DG_ACC_REBUILD, 0.5)])
+    h1 = O.gcn_layer(s, d, n, x * 0.1, slope=0.5)
+    h2 = O.gcn_layer(s, d, n, h1, slope=0.5)
+    want = x * 0.1 + torch.nn.functional.normalize(h1, p=2, dim=1) + torch.nn.functional.normalize(h2, p=2, dim=1)
+    assert_rows_close(acc, want, rtol=2e-5, what=what + " two layers")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_propagation_backward_random_graphs(seed):
+    """d e0 of <ui, R1> + <het, R2> through HGDM.propagate on random behaviour graphs (power-law items, a small or
+    a large item side, varied schedule knobs) against torch autograd on the oracle evaluated in fp64."""
+    rng = np.random.default_rng(2000 + seed)
+    nu = int(rng.integers(40, 2500)) if seed % 2 == 0 else int(rng.integers(6000, 9000))
+    ni = int(rng.integers(40, 2500)) if seed % 2 == 0 else int(rng.integers(2, 80))
+    inter = []
+    for b in range(3):
+        m = int(rng.integers(nu, 12 * nu))
+        w = 1.0 / np.arange(1, ni + 1) ** rng.uniform(0.5, 1.3)
+        key = np.unique(rng.integers(0, nu, m).astype(np.int64) * ni + rng.choice(ni, m, p=w / w.sum()))
+        inter.append(((key // ni).astype(np.int32), (key % ni).astype(np.int32)))
+    knobs = dict(group_max=int(rng.choice([0, 4, 64])), seg_len=int(rng.choice([0, 64])))
+    graphs = [graph_of(u, i, nu, ni, **knobs) for (u, i) in inter]
+    from types import SimpleNamespace
+    m_ = dg.rec.HGDM(SimpleNamespace(userNum=nu, itemNum=ni, target_adj=graphs[0], behavior_mats=graphs[1:])).eval()
+    gen = torch.Generator().manual_seed(seed)
+    ue, ie = torch.randn(nu, 64, generator=gen) * 0.1, torch.randn(ni, 64, generator=gen) * 0.1
+    m_.set_embeddings(dev(ue), dev(ie))
+    r1, r2 = torch.randn(nu + ni, 64, generator=gen), torch.randn(nu + ni, 64, generator=gen)
+    ui, het = m_.propagate(m_.embedding_table)
+    ((ui * dev(r1)).sum() + (het * dev(r2)).sum()).backward()
+    # the oracle in fp64: with item rows of 10^3..10^4 neighbours its own fp32 autograd is 7e-4 off in places
+    # (sequential index_add_ sums), the kernels' fixed-order partial sums 3e-7
+    ue_, ie_ = ue.double().requires_grad_(True), ie.double().requires_grad_(True)
+    tu, ti, hu, hi = O.rec_forward(edges_t(*inter[0], nu), [edges_t(*b, nu) for b in inter[1:]], ue_, ie_, 2)
+    assert_rows_close(ui, torch.cat([tu, ti]), what=f"seed {seed} forward")
+    ((torch.cat([tu, ti]) * r1.double()).sum() + (torch.cat([hu, hi]) * r2.double()).sum()).backward()
+    assert_rows_close(m_.embedding_table.grad, torch.cat([ue_.grad, ie_.grad]), rtol=2e-5,
+                      what=f"seed {seed} d e0 ({nu} x {ni}, {knobs})")
