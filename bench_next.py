@@ -405,18 +405,8 @@ def bench_epoch(workload: str, steps: int, warmup: int, cpu_baseline: bool):
                         "traffic": None, "kernel": "gcn_layer_kernel + hub_reduce_kernel (one fused propagation layer, all graphs)",
                         "bytes_per_launch": layer_bytes, "ms_per_launch": layer_ms}}
     if cpu_baseline:
-        from oracle import ref_cpu as O      # the CPU baseline leg: the only use of the oracle here
-        T = torch.from_numpy
-        ue, ie = T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))
-        mk = lambda ui: tuple(T(a.astype(np.int64)) for a in dgdata.bipartite_edges(ui[0], ui[1], nu))
-        target, behs = mk(wl.target), [mk(b) for b in wl.behaviours]
-        O.rec_forward(target, behs, ue, ie, L)
-        t0, k = time.perf_counter(), 0
-        while time.perf_counter() - t0 < 10.0:
-            O.rec_forward(target, behs, ue, ie, L)
-            k += 1
-        el = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": k * L * sum(nnz) / el, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"{k} forward propagation passes of the {workload} workload (index_add_ form), torch CPU, "
-                                         f"{el:.1f} s; an epoch of the reference adds the backward pass, {n_batches} times"}
+        import bench      # (bench.cpu_baseline is the one place that times the oracle's propagation: index_add_ and CSR forms)
+        res["cpu_baseline"] = bench.cpu_baseline(wl)
+        res["cpu_baseline"]["sample"] += (f"; forward propagation only -- an epoch of the reference adds the backward pass, "
+                                          f"{n_batches} times, and its Python-side sampling and evaluation")
     return res
