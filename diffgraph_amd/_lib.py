@@ -112,6 +112,9 @@ SIGNATURES = {
     "dg_denoiser_wgrad_workspace": (C.c_size_t, [C.c_int32]),
     "dg_denoiser_wgrad": (C.c_int, [C.POINTER(Denoiser), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_size_t] + [C.c_void_p] * 7),
+    "dg_denoiser_wgrad_static_max_steps": (C.c_int32, []),
+    "dg_denoiser_wgrad_static": (C.c_int, [C.POINTER(Denoiser), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_int32] +
+                                 [C.c_void_p] * 7),
     "dg_denoiser_wgrad_batched": (C.c_int, [C.POINTER(WgradTask), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dg_eval_topk_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "dg_eval_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,

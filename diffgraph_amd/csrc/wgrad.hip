@@ -18,6 +18,7 @@
 #include "dg_internal.h"
 
 #include <math.h>
+#include <mutex>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -316,4 +317,52 @@ extern "C" int dg_denoiser_wgrad(const dg_denoiser *dn, int32_t n_steps, const i
   t.workspace = workspace; t.workspace_bytes = workspace_bytes;
   t.d_w_emb = d_w_emb; t.d_b_emb = d_b_emb; t.d_w_in = d_w_in; t.d_b_in = d_b_in; t.d_w_out = d_w_out; t.d_b_out = d_b_out;
   return dg_denoiser_wgrad_batched(&t, 1, n_steps, d, stream);
+}
+
+// -- the same without a workspace argument, for callers that cannot allocate --------------------------
+// The workspace of dg_denoiser_wgrad (timestep operand table, one partial result per workgroup of the
+// partial launch) lives in the code object's own device memory, sized for kStaticMaxSteps timesteps.
+// Every GPU the library runs on holds its own copy of the array, at its own address, until the process ends.
+namespace {
+constexpr int kStaticMaxSteps = 1024;
+constexpr size_t kStaticFloats = (size_t)kStaticMaxSteps * kTabCols + 64 * 8 + (size_t)kGroups * kPartFloats;
+static __device__ __align__(256) float scratch[kStaticFloats];   // 9.19 MiB
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+float *g_scratch_ptr[kMaxDevices];   // device address of `scratch` on each device, looked up on first use
+
+// The array's name is only a host-side handle: its device address on the current device comes from the runtime.
+int scratch_on_current_device(float **out) {
+  int dev = -1;
+  DG_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad_static: device %d not supported (max %d)", dev, kMaxDevices);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    float *p = nullptr;
+    DG_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+    if (!p) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad_static: no device address for the scratch array");
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
+extern "C" int32_t dg_denoiser_wgrad_static_max_steps(void) { return kStaticMaxSteps; }
+
+extern "C" int dg_denoiser_wgrad_static(const dg_denoiser *dn, int32_t n_steps, const int64_t *ts, const float *dout_tot,
+                                        const float *hid, const float *dpre, const float *xn, int64_t n, int32_t d,
+                                        float *d_w_emb, float *d_b_emb, float *d_w_in, float *d_b_in, float *d_w_out,
+                                        float *d_b_out, void *stream) {
+  if (n_steps > kStaticMaxSteps)
+    return dg_fail(DG_ERR_SIZE, "dg_denoiser_wgrad_static: %d timesteps exceed the built-in scratch (at most %d); use "
+                   "dg_denoiser_wgrad with a workspace", n_steps, kStaticMaxSteps);
+  float *ws = nullptr;
+  int rc = scratch_on_current_device(&ws);
+  if (rc) return rc;
+  // Nothing in the scratch has to start at zero: the table kernel writes all n_steps operand rows, every workgroup
+  // of the partial launch writes its whole partial result (zeros when it has no rows), the finalize launch all of mk.
+  return dg_denoiser_wgrad(dn, n_steps, ts, dout_tot, hid, dpre, xn, n, d, ws, kStaticFloats * sizeof(float), d_w_emb,
+                           d_b_emb, d_w_in, d_b_in, d_w_out, d_b_out, stream);
 }

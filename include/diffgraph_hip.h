@@ -323,6 +323,19 @@ int dg_denoiser_wgrad(const dg_denoiser *dn, int32_t n_steps, const int64_t *ts,
                       void *workspace, size_t workspace_bytes, float *d_w_emb, float *d_b_emb,
                       float *d_w_in, float *d_b_in, float *d_w_out, float *d_b_out, void *stream);
 
+/* dg_denoiser_wgrad without the workspace argument.  No counterpart in the reference: it is for callers
+ * that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  The scratch (timestep operand table + per-workgroup partial results, 9.2 MiB) is a
+ * device array inside the library, one copy per GPU, held until the process ends; the call allocates and
+ * frees nothing.  n_steps must not exceed dg_denoiser_wgrad_static_max_steps() (1024), else DG error -3.
+ * Same kernels and summation order as dg_denoiser_wgrad: same bits.  All calls on one GPU share that GPU's
+ * scratch: calls that overlap on one GPU (different streams or threads) race; serialise them. */
+int32_t dg_denoiser_wgrad_static_max_steps(void);
+int dg_denoiser_wgrad_static(const dg_denoiser *dn, int32_t n_steps, const int64_t *ts, const float *dout_tot,
+                             const float *hid, const float *dpre, const float *xn, int64_t n, int32_t d,
+                             float *d_w_emb, float *d_b_emb, float *d_w_in, float *d_b_in, float *d_w_out,
+                             float *d_b_out, void *stream);
+
 /* The same for up to two denoisers (a training step's usr_denoiser and item_denoiser,
  * DiffGraph-Rec/Model.py:34-35) in one set of four launches; every task brings its own workspace. */
 typedef struct dg_wgrad_task {
