@@ -171,14 +171,42 @@ def cpu_spmm_variants(edges, n, x, budget_s=2.0):
     return out
 
 
+def launch_ranks(n: int) -> int:
+    """Runs this command line as N ranks, one per GPU, under torch.distributed.run on this node; relays rank 0's JSON
+    line (the ranks' other output goes to stderr) and returns non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    records = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if ln not in records:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"bench.py: torch.distributed.run exited with code {proc.returncode}", file=sys.stderr)
+        return proc.returncode
+    if len(records) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(records)}", file=sys.stderr)
+        return 1
+    print(records[0])
+    return 0
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks (nothing has touched the GPU yet in this process)
+        raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(n_dev, 1)  # (> 1 rank per GPU only happens in single-GPU rehearsals over gloo)
     torch.cuda.set_device(dev_index)

@@ -125,10 +125,11 @@ def all_gather_start(t: torch.Tensor, world: int, group=None, out: Optional[torc
     enqueued (on the communicator's own stream, after everything already enqueued on the current stream): kernels
     launched before `wait()` run beside it."""
     import torch.distributed as dist
-    if world > 1 and t.is_cuda and dist.get_backend(group) != "gloo":
+    if world > 1 and (t.is_cuda != (dist.get_backend(group) == "gloo")):   # RCCL on GPU tensors, gloo on host tensors
         if out is None:
             out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        return _Pending(out, dist.all_gather_into_tensor(out, t.contiguous(), group=group, async_op=True))
+        flat = out.view((world * t.shape[0],) + tuple(t.shape[1:]))    # the concatenated form: every backend takes it
+        return _Pending(out, dist.all_gather_into_tensor(flat, t.contiguous(), group=group, async_op=True))
     res = all_gather_stack(t, world, group)
     if out is None:
         return _Pending(res)
@@ -321,9 +322,24 @@ class ShardedRecPropagation:
 # --------------------------------------------------------------------------------------
 # bench.py leg for --gpus N > 1 (and for --workload industry at N = 1)
 # --------------------------------------------------------------------------------------
-def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
+class _HostEvent:
+    """Stand-in for a HIP event when the leg runs on host tensors (the gloo tests): wall-clock stamps."""
+
+    def __init__(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other: "_HostEvent") -> float:
+        return (other.t - self.t) * 1e3
+
+
+def bench_sharded(args, rank: int, world: int, device, backend=None) -> Optional[dict]:
+    """The sharded-propagation leg of bench.py.  `backend` defaults to the HIP kernels on `device`; the tests pass
+    a host backend and a cpu device to run the same control flow over gloo."""
     from . import data as dgdata
     import torch.distributed as dist
+    device = torch.device(device)
+    on_gpu = device.type == "cuda"
+    backend = backend or HipBackend(device)
     workload = args.workload or "industry"
     wl = dgdata.rec_workload(workload)
     inter = [wl.target] + wl.behaviours
@@ -334,10 +350,10 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
     def make(rk, wd):
         if row_blocks:
             edges = [dgdata.bipartite_edges(u, i, wl.n_user) for (u, i) in inter]
-            p = RowBlockPropagation(edges, wl.n, rk, wd, HipBackend(device))
+            p = RowBlockPropagation(edges, wl.n, rk, wd, backend)
             full = torch.cat([torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)), ie])
             return p, full[p.r0:p.r1].to(device)
-        p = ShardedRecPropagation(inter, wl.n_user, wl.n_item, rk, wd, HipBackend(device), reuse_buffers=True)
+        p = ShardedRecPropagation(inter, wl.n_user, wl.n_item, rk, wd, backend, reuse_buffers=True)
         ue = torch.from_numpy(dgdata.xavier_uniform(wl.n_user, 64, seed=0)[p.u0:p.u1])
         return p, torch.cat([ue, ie]).to(device)
     prop, e0 = make(rank, world)
@@ -346,17 +362,24 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
 
     def hook(phase, layer=None):
         if hook.enabled:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record(torch.cuda.current_stream())
+            if on_gpu:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream())
+            else:
+                ev = _HostEvent()
             events.append(ev)
     hook.enabled = False
     prop.hook = hook
 
+    def device_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
     def sync():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            device_sync()
 
     for _ in range(args.warmup):
         prop.forward(e0)
@@ -374,7 +397,7 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
     hook.enabled = True
     for _ in range(max(10, args.steps // 2)):
         prop.forward(e0)
-    torch.cuda.synchronize()
+    device_sync()
     hook.enabled = False
     L = prop.n_layers
     # row blocks: one event pair per layer; user-row shards: one pair round the layers of a forward pass (they interleave)
@@ -396,11 +419,11 @@ def bench_sharded(args, rank: int, world: int, device) -> Optional[dict]:
         p1, e1 = make(0, 1)
         for _ in range(max(2, args.warmup // 2)):
             p1.forward(e1)
-        torch.cuda.synchronize()
+        device_sync()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             p1.forward(e1)
-        torch.cuda.synchronize()
+        device_sync()
         single = L * sum(nnz) * args.steps / (time.perf_counter() - t1)
 
     res = None

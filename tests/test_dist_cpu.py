@@ -129,3 +129,55 @@ def test_row_block_forward_matches_oracle(world):
     het = np.concatenate([r[4] for r in results])
     assert_rows_close(ui, torch.cat([tu, ti]), what="row-block target")
     assert_rows_close(het, torch.cat([hu, hi]), what="row-block heter")
+
+
+# ---------------------------------------------------------------- the bench leg for --gpus N, end to end over gloo
+def _bench_worker(rank, world, port, q):
+    from types import SimpleNamespace
+    from diffgraph_amd import dist as dgdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    calls = []
+
+    class Recording(CpuBackend):     # the order of the launches and exchanges of one forward pass, as this rank issues them
+        def prepare_layer(self, tasks):
+            kind = "partial" if tasks[0]["flags"] & dgdist.DG_ROWS_PARTIAL_ONLY else "full" if tasks[0]["flags"] & dgdist.DG_ROWS_FULL_ONLY else "layer"
+            fn = super().prepare_layer(tasks)
+            return lambda: (calls.append(kind), fn())
+
+        def prepare_finalize(self, tasks):
+            fn = super().prepare_finalize(tasks)
+            return lambda: (calls.append("finalize"), fn())
+    start, wait = dgdist.all_gather_start, dgdist._Pending.wait
+    dgdist.all_gather_start = lambda *a, **k: (calls.append("start"), start(*a, **k))[1]
+    dgdist._Pending.wait = lambda self: (calls.append("wait"), wait(self))[1]
+    args = SimpleNamespace(workload="tiny", steps=3, warmup=1)
+    res = dgdist.bench_sharded(args, rank, world, "cpu", backend=Recording())
+    q.put((rank, res, calls[:10]))
+
+
+def test_bench_sharded_runs_end_to_end_over_gloo():
+    """bench.py's multi-rank leg (diffgraph_amd.dist.bench_sharded) with two gloo ranks on host tensors: one JSON
+    record from rank 0 with the whole-job rate and the one-rank comparison, and the split-row order of a forward
+    pass -- item partial sums, exchange started, user rows beside it, next layer's partial sums ahead of this
+    layer's wait + finalize."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict((r[0], r[1:]) for r in (q.get(timeout=180) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res, calls = results[0]
+    assert results[1][0] is None                      # only rank 0 reports
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["value"] > 0 and res["unit"] == "edges/s"
+    assert res["config"]["speedup_over_1gpu"] > 0 and res["config"]["parallelism"] == "user-row shards x2"
+    assert res["roofline"]["ms_per_launch"] > 0
+    # forward pass of 2 layers: A1 start (B1 | A2 start) wait F1 B2 wait F2
+    assert calls == ["partial", "start", "full", "partial", "start", "wait", "finalize", "full", "wait", "finalize"]
+    assert results[1][1] == calls

@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*args):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=300)
+def _run(*args, env=None):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
@@ -36,3 +37,12 @@ def test_training_step_line_on_the_tiny_workload():
 def test_eager_step_gives_the_same_kind_of_line():
     r = _run("--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline")
     assert r["config"]["launch"] == "eager" and "cpu_baseline" not in r and r["value"] > 0
+
+
+def test_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself and relays rank 0's
+    line.  (Both ranks share this box's one GPU and exchange over gloo: a rehearsal of the control flow, not a
+    measurement.)"""
+    r = _run("--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", env={"DG_DIST_BACKEND": "gloo"})
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0
+    assert r["config"]["speedup_over_1gpu"] > 0 and "x2" in r["config"]["parallelism"]
