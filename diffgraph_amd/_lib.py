@@ -59,7 +59,7 @@ class LossTask(C.Structure):
                 ("noise", C.c_void_p), ("ts", C.c_void_p), ("n", C.c_int64), ("out", C.c_void_p), ("row_loss", C.c_void_p),
                 ("g_row_loss", C.c_void_p), ("g_out", C.c_void_p), ("d_target_add", C.c_void_p), ("d_x_start", C.c_void_p),
                 ("d_target", C.c_void_p), ("dout_tot", C.c_void_p), ("hid", C.c_void_p), ("dpre", C.c_void_p),
-                ("xn", C.c_void_p)]
+                ("xn", C.c_void_p), ("keep_mask", C.c_void_p), ("drop_seed", C.c_void_p), ("drop_p", C.c_float)]
 
 
 class WgradTask(C.Structure):
@@ -109,6 +109,7 @@ SIGNATURES = {
                                                 C.c_int32, C.c_void_p]),
     "dg_diffusion_loss_bwd_batched": (C.c_int, [C.POINTER(LossTask), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int32, C.c_void_p]),
+    "dg_dropout_keep_mask": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "dg_denoiser_wgrad_workspace": (C.c_size_t, [C.c_int32]),
     "dg_denoiser_wgrad": (C.c_int, [C.POINTER(Denoiser), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_size_t] + [C.c_void_p] * 7),

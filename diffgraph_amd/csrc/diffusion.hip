@@ -16,6 +16,7 @@
 // the whole 200-step reverse loop is one launch with no memory traffic inside the loop
 // beyond 256 B of bias per step.
 #include "dg_internal.h"
+#include "dg_philox.h"
 
 #include <math.h>
 
@@ -50,6 +51,11 @@ struct dn_task {
   float *d_x_start, *d_target;        // [n][64]
   const float *d_target_add;          // [n][64] added into d_target (a gradient that reached the target elsewhere), or NULL
   float *dout_tot, *hid, *dpre, *xn;  // [n][64] each: operands of the weight-gradient GEMMs
+  // dropout between F.normalize and the first Linear (LOSS and its backward; Model.py:221-224)
+  const uint8_t *keep_mask;           // [n][64], nonzero = kept; NULL: drawn from drop_seed
+  const int64_t *drop_seed;           // one device word: the key of the draw
+  float drop_scale;                   // 1 / (1 - p); 0: no dropout
+  uint32_t drop_thr, drop_stream;     // kept iff the element's random byte >= drop_thr; stream = task number
   int64_t n;
   int32_t n_steps, norm, blk_begin;
 };
@@ -100,10 +106,40 @@ __device__ __forceinline__ void contract64(const f32x4 *__restrict__ wl, int lan
     }
 }
 
-// One Denoise.forward on the 32-row tile held in xs: F.normalize, in-layer + tanh, out-layer.
+// The 32 random bytes of one (row, lane half): element tau*16 + 4q + e of the lane's tile uses byte number
+// 4 (4 tau + q) + e.  Two Philox calls keyed by the seed word; the counter names the row, the half and the stream.
+__device__ __forceinline__ void drop_bytes(uint64_t seed, uint32_t stream, int64_t row, int h, uint32_t (&w)[8]) {
+  const dg_u32x4 a = dg_philox4x32_10((uint32_t)row, (uint32_t)((uint64_t)row >> 32), 2u * h, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const dg_u32x4 b = dg_philox4x32_10((uint32_t)row, (uint32_t)((uint64_t)row >> 32), 2u * h + 1u, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+
+// nn.Dropout's multiplier for the lane's tile: 1/(1-p) where the element is kept, 0 where it is dropped.
+__device__ __forceinline__ void drop_tile(const dn_task &T, int64_t row, int h, bool valid, f32x16 (&m)[2]) {
+  uint32_t w[8];
+  if (T.keep_mask != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      w[c] = 0;
+      if (valid) w[c] = *reinterpret_cast<const uint32_t *>(T.keep_mask + row * DG_D + 32 * (c >> 2) + 8 * (c & 3) + 4 * h);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[c >> 2][4 * (c & 3) + e] = ((w[c] >> (8 * e)) & 0xffu) ? T.drop_scale : 0.f;
+    return;
+  }
+  drop_bytes((uint64_t)T.drop_seed[0], T.drop_stream, row, h, w);
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[c >> 2][4 * (c & 3) + e] = ((w[c] >> (8 * e)) & 0xffu) >= T.drop_thr ? T.drop_scale : 0.f;
+}
+
+// One Denoise.forward on the 32-row tile held in xs: F.normalize, (dropout,) in-layer + tanh, out-layer.
 __device__ __forceinline__ void denoise_tile(const f32x4 *__restrict__ wl, int lane, int h, bool norm,
                                              const float *__restrict__ tb_row, const float *__restrict__ b_out,
-                                             const f32x16 (&xs)[2], f32x16 (&out)[2]) {
+                                             const f32x16 (&xs)[2], f32x16 (&out)[2], const f32x16 *drop = nullptr) {
   f32x16 xn[2] = {xs[0], xs[1]};
   if (norm) {
     float ss = 0.f;
@@ -115,6 +151,10 @@ __device__ __forceinline__ void denoise_tile(const f32x4 *__restrict__ wl, int l
     const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
     xn[0] = xs[0] * inv;
     xn[1] = xs[1] * inv;
+  }
+  if (drop != nullptr) {
+    xn[0] *= drop[0];
+    xn[1] *= drop[1];
   }
   f32x16 hid[2];
   load_tile(tb_row, h, true, hid);  // accumulator starts at b_in + W_in[:,64:72].emb(t)
@@ -178,7 +218,13 @@ __global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch bat
     xs[1] = a * xs[1] + s * nz[1];
     if (T.x_t_out) store_tile(T.x_t_out + row * DG_D, h, valid, xs);
   }
-  denoise_tile(wl, lane, h, norm, T.time_bias + t * DG_D, T.b_out, xs, out);
+  if (MODE == MODE_LOSS && T.drop_scale != 0.f) {
+    f32x16 m[2];
+    drop_tile(T, row, h, valid, m);
+    denoise_tile(wl, lane, h, norm, T.time_bias + t * DG_D, T.b_out, xs, out, m);
+  } else {
+    denoise_tile(wl, lane, h, norm, T.time_bias + t * DG_D, T.b_out, xs, out);
+  }
   store_tile(T.out + row * DG_D, h, valid, out);
   if (MODE == MODE_LOSS) {  // mean_flat((target-out)^2) * (SNR(t-1)-SNR(t)) (Model.py:360-364)
     f32x16 tg[2];
@@ -198,8 +244,7 @@ __global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch bat
 
 // Backward of training_losses2 for a 32-row tile per wavefront: recomputes the forward
 // (q_sample, normalise, two contractions, tanh), then runs the two transposed contractions.
-// Weight gradients are left to two [64 x n].[n x 64] library GEMMs over the stored
-// dout_tot / hid / dpre / xn tables.
+// The weight gradients are formed by dg_denoiser_wgrad from the dout_tot / hid / dpre / xn tables stored here.
 __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch batch) {
   // images 0,1: W_in[:, :64], W_out (as in denoise_kernel); 2: W_out^T; 3: W_in[:, :64]^T
   __shared__ f32x4 wl[4 * 2 * 2 * 4 * 64];
@@ -255,10 +300,18 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
     xn[0] = xs[0] * inv;
     xn[1] = xs[1] * inv;
   }
-  store_tile(T.xn + ro, h, valid, xn);
+  const bool drop = T.drop_scale != 0.f;
+  f32x16 xd[2] = {xn[0], xn[1]};   // what the first Linear sees: the normalised row after dropout
+  f32x16 dm[2];
+  if (drop) {
+    drop_tile(T, row, h, valid, dm);
+    xd[0] *= dm[0];
+    xd[1] *= dm[1];
+  }
+  store_tile(T.xn + ro, h, valid, xd);
   f32x16 hid[2], out[2];
   load_tile(T.time_bias + t * DG_D, h, true, hid);
-  contract64(wl, lane, xn, hid);
+  contract64(wl, lane, xd, hid);
 #pragma unroll
   for (int tau = 0; tau < 2; ++tau)
 #pragma unroll
@@ -303,6 +356,10 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
   f32x16 dx[2];
   dx[0] = dx[1] = f32x16{0.f};
   contract64(wl + 3 * 1024, lane, dh, dx);
+  if (drop) {
+    dx[0] *= dm[0];
+    dx[1] *= dm[1];
+  }
   if (T.norm) {
     float ng = 0.f;
 #pragma unroll
@@ -546,6 +603,14 @@ int fill_loss_task(const char *who, const dg_loss_task &t, int32_t n_steps, int3
   k.w_in = t.dn->w_in; k.w_out = t.dn->w_out; k.b_out = t.dn->b_out; k.time_bias = t.time_bias;
   k.x = t.x_start; k.noise = t.noise; k.target = t.target; k.t = t.ts; k.sqrt_ac = sqrt_ac; k.sqrt_1mac = sqrt_1mac;
   k.loss_w = loss_w; k.n = t.n; k.n_steps = n_steps; k.norm = t.dn->norm;
+  if (t.drop_p != 0.f) {
+    if (!(t.drop_p > 0.f && t.drop_p < 1.f)) return dg_fail(DG_ERR_ARG, "%s: drop_p must lie in [0,1) (got %g)", who, (double)t.drop_p);
+    if (!t.keep_mask && !t.drop_seed) return dg_fail(DG_ERR_ARG, "%s: dropout needs keep_mask or drop_seed", who);
+    if (t.keep_mask && ((uintptr_t)t.keep_mask & 3)) return dg_fail(DG_ERR_ARG, "%s: keep_mask must be 4-byte aligned", who);
+    k.keep_mask = t.keep_mask; k.drop_seed = t.drop_seed;
+    k.drop_scale = 1.0f / (float)(1.0 - (double)t.drop_p);
+    k.drop_thr = (uint32_t)lrint((double)t.drop_p * 256.0);
+  }
   if (!bwd) {
     if (!t.out || !t.row_loss) return dg_fail(DG_ERR_ARG, "%s: NULL output", who);
     k.out = t.out; k.row_loss = t.row_loss;
@@ -571,6 +636,7 @@ int loss_batched(const char *who, const dg_loss_task *tasks, int32_t n_tasks, in
     if (rc) return rc;
     if (tasks[i].n == 0) continue;
     k.blk_begin = (int32_t)blocks;
+    k.drop_stream = (uint32_t)i;
     blocks += (tasks[i].n + kRowsPerBlock - 1) / kRowsPerBlock;
     batch.t[batch.n_tasks++] = k;
   }
@@ -595,4 +661,37 @@ extern "C" int dg_diffusion_loss_bwd_batched(const dg_loss_task *tasks, int32_t 
                                              void *stream) {
   return loss_batched("dg_diffusion_loss_bwd_batched", tasks, n_tasks, n_steps, sqrt_ac, sqrt_1mac, loss_w, d, true,
                       (hipStream_t)stream);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void keep_mask_kernel(const int64_t *__restrict__ seed, uint32_t stream, uint32_t thr, int64_t n,
+                                                        uint8_t *__restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (row, lane half)
+  if (i >= 2 * n) return;
+  const int64_t row = i >> 1;
+  const int h = (int)(i & 1);
+  uint32_t w[8];
+  drop_bytes((uint64_t)seed[0], stream, row, h, w);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o |= (((w[c] >> (8 * e)) & 0xffu) >= thr ? 1u : 0u) << (8 * e);
+    *reinterpret_cast<uint32_t *>(mask + row * DG_D + 32 * (c >> 2) + 8 * (c & 3) + 4 * h) = o;
+  }
+}
+}  // namespace
+
+extern "C" int dg_dropout_keep_mask(const int64_t *drop_seed, int32_t task, float drop_p, int64_t n, int32_t d, uint8_t *mask,
+                                    void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_dropout_keep_mask: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!drop_seed || !mask || n < 0 || task < 0) return dg_fail(DG_ERR_ARG, "dg_dropout_keep_mask: bad argument");
+  if (!(drop_p > 0.f && drop_p < 1.f)) return dg_fail(DG_ERR_ARG, "dg_dropout_keep_mask: drop_p must lie in (0,1)");
+  if ((uintptr_t)mask & 3) return dg_fail(DG_ERR_ARG, "dg_dropout_keep_mask: mask must be 4-byte aligned");
+  if (n == 0) return 0;
+  const int64_t blocks = (2 * n + 255) / 256;
+  hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, drop_seed, (uint32_t)task,
+                     (uint32_t)lrint((double)drop_p * 256.0), n, mask);
+  DG_HIP(hipGetLastError());
+  return 0;
 }

@@ -8,23 +8,9 @@
 // seed, counter = pair index and attempt), so a given (seed, pair) always yields the same negative
 // whatever the launch shape.
 #include "dg_internal.h"
+#include "dg_philox.h"
 
 namespace {
-
-struct u32x4_t { uint32_t x, y, z, w; };
-
-__device__ __forceinline__ u32x4_t philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += W0; k1 += W1;
-  }
-  return {c0, c1, c2, c3};
-}
 
 // Uniform integer in [0, n) from 32 random bits: multiply-shift with rejection of the biased low range.
 __device__ __forceinline__ bool bounded(uint32_t r, uint32_t n, uint32_t &out) {
@@ -50,7 +36,7 @@ __global__ __launch_bounds__(256) void neg_sampling_kernel(const int32_t *__rest
     return;
   }
   for (uint32_t attempt = 0;; ++attempt) {
-    const u32x4_t r = philox4x32_10((uint32_t)p, (uint32_t)(p >> 32), attempt, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const dg_u32x4 r = dg_philox4x32_10((uint32_t)p, (uint32_t)(p >> 32), attempt, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
     const uint32_t draws[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -73,13 +73,28 @@ class Denoise(nn.Module):
         return ops.denoise_fwd(p, x.contiguous(), timesteps, n_steps)
 
 
+def dropout_args(models, keep_mask, device):
+    """(drop_p, keep_mask, drop_seed) for a loss call through `models` (Denoise modules): dropout is on when they are
+    in training mode with p > 0 (Model.py:223-224).  Without a caller-supplied mask a fresh key for the in-kernel
+    draw is taken from torch's generator (one int64 on the device, so a captured step draws a new mask per replay)."""
+    ps = {float(m.drop.p) if m.training else 0.0 for m in models}
+    if len(ps) != 1:
+        raise DiffGraphHipError("the denoisers of one loss call must share their training mode and dropout rate")
+    p = ps.pop()
+    if p <= 0.0:
+        return 0.0, None, None
+    if keep_mask is not None:
+        return p, keep_mask.contiguous().view(torch.uint8) if keep_mask.dtype == torch.bool else keep_mask.contiguous(), None
+    return p, None, torch.randint(0, 2 ** 62, (1,), device=device, dtype=torch.int64)
+
+
 class _DiffusionLossFn(torch.autograd.Function):
     """training_losses2 as one differentiable op: HIP kernels for the per-row work in both
     directions, the weight gradients included (ops.denoiser_wgrad over tables the backward
     kernel writes)."""
 
     @staticmethod
-    def forward(ctx, target, x_start, noise, ts, w_emb, b_emb, w_in, b_in, w_out, b_out, gd, model, validate):
+    def forward(ctx, target, x_start, noise, ts, w_emb, b_emb, w_in, b_in, w_out, b_out, gd, model, validate, drop):
         dev = x_start.device
         p = model.params(bool(model.norm))
         p.time_bias(gd.steps, refresh=True)
@@ -87,24 +102,28 @@ class _DiffusionLossFn(torch.autograd.Function):
         sb = gd._dev("sqrt_one_minus_alphas_cumprod", dev) if gd.noise_scale != 0 else None
         lw = gd._dev("loss_weight", dev, torch.float64)
         target, x_start = target.contiguous(), x_start.contiguous()
-        row_loss, out, _ = ops.diffusion_loss_fwd(p, target, x_start, noise, ts, sa, sb, lw, validate=validate)
+        drop_p, keep_mask, drop_seed = drop
+        spans = [ops.LossSpan(p, 0, x_start.shape[0], drop_p)]
+        row_loss, out = ops.diffusion_loss_fwd_spans(spans, target, x_start, noise, ts, sa, sb, lw, validate=validate,
+                                                     keep_mask=keep_mask, drop_seed=drop_seed)
         ctx.save_for_backward(target, x_start, noise if noise is not None else x_start, ts)
-        ctx.aux = (gd, model, p, sa, sb, lw)
+        ctx.aux = (gd, spans, sa, sb, lw, keep_mask, drop_seed)
         return row_loss, out
 
     @staticmethod
     def backward(ctx, g_row, g_out):
         target, x_start, noise, ts = ctx.saved_tensors
-        gd, model, p, sa, sb, lw = ctx.aux
+        gd, spans, sa, sb, lw, keep_mask, drop_seed = ctx.aux
         dev = x_start.device
         n = x_start.shape[0]
         if g_row is None:
             g_row = torch.zeros(n, dtype=torch.float64, device=dev)
         g_out = None if g_out is None else g_out.contiguous()
-        d_x, d_tgt, dout, hid, dpre, xn = ops.diffusion_loss_bwd(p, target, x_start, noise, ts, sa, sb, lw,
-                                                                 g_row.contiguous(), g_out)
-        d_w_emb, d_b_emb, d_w_in, d_b_in, d_w_out, d_b_out = ops.denoiser_wgrad(p, gd.steps, ts, dout, hid, dpre, xn)
-        return d_tgt, d_x, None, None, d_w_emb, d_b_emb, d_w_in, d_b_in, d_w_out, d_b_out, None, None, None
+        d_x, d_tgt, dout, hid, dpre, xn = ops.diffusion_loss_bwd_spans(spans, target, x_start, noise, ts, sa, sb, lw,
+                                                                       g_row.contiguous(), g_out, keep_mask=keep_mask,
+                                                                       drop_seed=drop_seed)
+        d_w_emb, d_b_emb, d_w_in, d_b_in, d_w_out, d_b_out = ops.denoiser_wgrad(spans[0].dn, gd.steps, ts, dout, hid, dpre, xn)
+        return d_tgt, d_x, None, None, d_w_emb, d_b_emb, d_w_in, d_b_in, d_w_out, d_b_out, None, None, None, None
 
 
 class GaussianDiffusion(nn.Module):
@@ -132,14 +151,10 @@ class GaussianDiffusion(nn.Module):
 
     def calculate_for_diffusion(self):  # Model.py:268-285
         alphas = 1.0 - self.betas
-        self.alphas_cumprod = torch.cumprod(alphas, axis=0)
+        self.alphas_cumprod = torch.cumprod(alphas, dim=0)
         self.alphas_cumprod_prev = torch.cat([torch.tensor([1.0], dtype=torch.float64), self.alphas_cumprod[:-1]])
-        self.alphas_cumprod_next = torch.cat([self.alphas_cumprod[1:], torch.tensor([0.0], dtype=torch.float64)])
         self.sqrt_alphas_cumprod = torch.sqrt(self.alphas_cumprod)
         self.sqrt_one_minus_alphas_cumprod = torch.sqrt(1.0 - self.alphas_cumprod)
-        self.log_one_minus_alphas_cumprod = torch.log(1.0 - self.alphas_cumprod)
-        self.sqrt_recip_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod)
-        self.sqrt_recipm1_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod - 1)
         self.posterior_variance = self.betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
         self.posterior_log_variance_clipped = torch.log(
             torch.cat([self.posterior_variance[1].unsqueeze(0), self.posterior_variance[1:]]))
@@ -212,13 +227,14 @@ class GaussianDiffusion(nn.Module):
         return ops.p_sample_loop_batched(prepared, self._dev("posterior_mean_coef1", dev),
                                          self._dev("posterior_mean_coef2", dev))
 
-    def training_losses2(self, model, targetEmbeds, x_start, batch, ts=None, noise=None):  # Model.py:348-366
-        row_loss, out = self.training_losses_rows(model, targetEmbeds, x_start, ts, noise)
+    def training_losses2(self, model, targetEmbeds, x_start, batch, ts=None, noise=None, keep_mask=None):  # Model.py:348-366
+        row_loss, out = self.training_losses_rows(model, targetEmbeds, x_start, ts, noise, keep_mask)
         return row_loss[batch], out
 
-    def training_losses_rows(self, model, targetEmbeds, x_start, ts=None, noise=None):
+    def training_losses_rows(self, model, targetEmbeds, x_start, ts=None, noise=None, keep_mask=None):
         """training_losses2 before its final `[batch]` gather (Model.py:348-365): the fp64 SNR-weighted loss of
-        EVERY row and the denoiser output."""
+        EVERY row and the denoiser output.  With `model` in training mode its dropout (Model.py:223-224) is applied
+        inside the kernels: to the elements `keep_mask` ([n, 64] bool / uint8) keeps, or to a fresh draw."""
         n = x_start.size(0)
         dev = x_start.device
         validate = ts is not None  # caller-supplied timesteps are range-checked (one host sync)
@@ -228,21 +244,19 @@ class GaussianDiffusion(nn.Module):
             noise = torch.randn_like(x_start)
         norm = bool(model.norm)
         xs = x_start.contiguous()
-        if model.training and model.drop.p > 0:
-            raise DiffGraphHipError("training-mode dropout inside training_losses2 is not fused; call model.eval() "
-                                    "(the reference runs with dropout off after its first epoch)")
+        drop = dropout_args([model], keep_mask, dev)
         if torch.is_grad_enabled() and (xs.requires_grad or targetEmbeds.requires_grad
                                         or any(q.requires_grad for q in model.parameters())):
             return _DiffusionLossFn.apply(
                 targetEmbeds, xs, noise, ts, model.emb_layer.weight, model.emb_layer.bias, model.in_layers[0].weight,
-                model.in_layers[0].bias, model.out_layers[0].weight, model.out_layers[0].bias, self, model, validate)
+                model.in_layers[0].bias, model.out_layers[0].weight, model.out_layers[0].bias, self, model, validate, drop)
         p = model.params(norm)
         p.time_bias(self.steps, refresh=True)
         sa = self._dev("sqrt_alphas_cumprod", dev) if self.noise_scale != 0 else None
         sb = self._dev("sqrt_one_minus_alphas_cumprod", dev) if self.noise_scale != 0 else None
-        row_loss, out, _ = ops.diffusion_loss_fwd(p, targetEmbeds.contiguous(), xs, noise, ts, sa, sb,
-                                                  self._dev("loss_weight", dev, torch.float64), validate=validate)
-        return row_loss, out
+        return ops.diffusion_loss_fwd_spans([ops.LossSpan(p, 0, n, drop[0])], targetEmbeds.contiguous(), xs, noise, ts, sa, sb,
+                                            self._dev("loss_weight", dev, torch.float64), validate=validate,
+                                            keep_mask=drop[1], drop_seed=drop[2])
 
     def mean_flat(self, tensor):  # Model.py:368-369
         return tensor.mean(dim=list(range(1, len(tensor.shape))))

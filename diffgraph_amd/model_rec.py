@@ -21,7 +21,7 @@ from torch import nn
 
 from . import ops
 from ._lib import DG_ACC_REBUILD, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
-from .diffusion import Denoise, GaussianDiffusion
+from .diffusion import Denoise, GaussianDiffusion, dropout_args
 from .layers import DGLLayer
 
 DEFAULT_ARGS = SimpleNamespace(latdim=64, gcn_layer=2, dims="[64]", d_emb_size=8, norm=True, steps=200,
@@ -107,36 +107,39 @@ class _RecLossFn(torch.autograd.Function):
     gradients of the two denoisers.  Returns fp64[4] = (loss, bprLoss, regLoss, diff_loss)."""
 
     @staticmethod
-    def forward(ctx, ui, het, noise, ts, ancs, poss, negs, model, validate, *weights):
+    def forward(ctx, ui, het, noise, ts, ancs, poss, negs, model, validate, drop, *weights):
         gd, args, nu = model.diffusion_process, model.args, model.n_user
         dev = ui.device
         ui, het = ui.contiguous(), het.contiguous()
+        drop_p, keep_mask, drop_seed = drop
         spans = []
         for dn, begin, n in ((model.usr_denoiser, 0, nu), (model.item_denoiser, nu, model.n_item)):
-            spans.append(ops.LossSpan(dn.params(bool(dn.norm)), begin, n))
+            spans.append(ops.LossSpan(dn.params(bool(dn.norm)), begin, n, drop_p))
         ops.refresh_time_bias([sp.dn for sp in spans], gd.steps)      # both denoisers' tables, one launch
         sa = gd._dev("sqrt_alphas_cumprod", dev) if gd.noise_scale != 0 else None
         sb = gd._dev("sqrt_one_minus_alphas_cumprod", dev) if gd.noise_scale != 0 else None
         lw = gd._dev("loss_weight", dev, torch.float64)
-        row_loss, out = ops.diffusion_loss_fwd_spans(spans, ui, het, noise, ts, sa, sb, lw, validate=validate)
+        row_loss, out = ops.diffusion_loss_fwd_spans(spans, ui, het, noise, ts, sa, sb, lw, validate=validate,
+                                                     keep_mask=keep_mask, drop_seed=drop_seed)
         results, ent_f = ops.rec_head_fwd(ui, out[:nu], out[nu:], row_loss[:nu], row_loss[nu:], ancs, poss, negs, nu,
                                           float(args.batch), float(args.reg))
         ctx.save_for_backward(ui, het, noise if noise is not None else het, ts, out, ancs, poss, negs, ent_f)
-        ctx.aux = (model, spans, sa, sb, lw)
+        ctx.aux = (model, spans, sa, sb, lw, keep_mask, drop_seed)
         return results
 
     @staticmethod
     def backward(ctx, g):
         ui, het, noise, ts, out, ancs, poss, negs, ent_f = ctx.saved_tensors
-        model, spans, sa, sb, lw = ctx.aux
+        model, spans, sa, sb, lw, keep_mask, drop_seed = ctx.aux
         gd, args, nu = model.diffusion_process, model.args, model.n_user
         d_ui_head, d_out, d_rl = ops.rec_head_bwd(ui, out[:nu], out[nu:], ancs, poss, negs, nu, float(args.batch),
                                                   float(args.reg), ent_f, g.contiguous(), full=True)
         d_het, d_ui, dout, hid, dpre, xn = ops.diffusion_loss_bwd_spans(spans, ui, het, noise, ts, sa, sb, lw, d_rl, d_out,
-                                                                        d_target_add=d_ui_head)
+                                                                        d_target_add=d_ui_head, keep_mask=keep_mask,
+                                                                        drop_seed=drop_seed)
         jobs = [(sp.dn,) + tuple(t[sp.begin: sp.begin + sp.n] for t in (ts, dout, hid, dpre, xn)) for sp in spans]
         grads = [g for res in ops.denoiser_wgrad_many(jobs, gd.steps) for g in res]   # both denoisers, one set of launches
-        return (d_ui, d_het, None, None, None, None, None, None, None) + tuple(grads)
+        return (d_ui, d_het, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
 class HGDM(nn.Module):
@@ -218,17 +221,21 @@ class HGDM(nn.Module):
         nu = self.n_user
         return ui[:nu], ui[nu:], het[:nu], het[nu:]
 
-    def cal_loss(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None):  # Model.py:94-111
-        res = self.cal_loss_vector(ancs, poss, negs, ts_u, noise_u, ts_i, noise_i)
+    def cal_loss(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None, keep_u=None, keep_i=None):  # Model.py:94-111
+        res = self.cal_loss_vector(ancs, poss, negs, ts_u, noise_u, ts_i, noise_i, keep_u, keep_i)
         return res[0], res[1], res[2], res[3]
 
-    def cal_loss_vector(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None) -> torch.Tensor:
+    def cal_loss_vector(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None, keep_u=None,
+                        keep_i=None, validate: Optional[bool] = None) -> torch.Tensor:
         """cal_loss as one float64[4] tensor (loss, bprLoss, regLoss, diff_loss).  `res.backward(e)` with
-        e = [1, 0, 0, 0] is `loss.backward()` without the kernels autograd spends on slicing the scalar out."""
+        e = [1, 0, 0, 0] is `loss.backward()` without the kernels autograd spends on slicing the scalar out.
+        In training mode the denoisers' dropout (Model.py:223-224) runs inside the loss kernels, over the
+        elements keep_u [n_user, 64] / keep_i [n_item, 64] keep (bool or uint8) or over a fresh draw."""
         ui, het = self.propagate(self.embedding_table)   # [users | items] tables: target-graph sums, behaviour sums
         dp = self.diffusion_process
         n = ui.shape[0]
-        validate = ts_u is not None or ts_i is not None  # caller-supplied timesteps are range-checked (one host sync)
+        if validate is None:   # caller-supplied timesteps are range-checked (one host sync) unless the caller vouches for them
+            validate = ts_u is not None or ts_i is not None
         if ts_u is None and ts_i is None:
             ts = torch.randint(0, dp.steps, (n,), device=ui.device).long()           # Model.py:352, both calls at once
         else:
@@ -236,16 +243,16 @@ class HGDM(nn.Module):
         noise = None
         if dp.noise_scale != 0:
             noise = torch.randn_like(ui) if noise_u is None and noise_i is None else torch.cat([noise_u, noise_i]).contiguous()
-        for dn in (self.usr_denoiser, self.item_denoiser):
-            if dn.training and dn.drop.p > 0:
-                raise ops.DiffGraphHipError("training-mode dropout inside training_losses2 is not fused; call model.eval() "
-                                            "(the reference runs with dropout off after its first epoch)")
+        keep = None
+        if keep_u is not None or keep_i is not None:
+            keep = torch.cat([keep_u.to(torch.uint8), keep_i.to(torch.uint8)]).contiguous()
+        drop = dropout_args([self.usr_denoiser, self.item_denoiser], keep, ui.device)
         ancs, poss, negs = (v.long().contiguous() for v in (ancs, poss, negs))
         weights = []
         for dn in (self.usr_denoiser, self.item_denoiser):
             weights += [dn.emb_layer.weight, dn.emb_layer.bias, dn.in_layers[0].weight, dn.in_layers[0].bias,
                         dn.out_layers[0].weight, dn.out_layers[0].bias]
-        return _RecLossFn.apply(ui, het, noise, ts, ancs, poss, negs, self, validate, *weights)
+        return _RecLossFn.apply(ui, het, noise, ts, ancs, poss, negs, self, validate, drop, *weights)
 
     def predict(self):  # Model.py:112-118
         usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = self.forward()

@@ -375,19 +375,49 @@ def diffusion_loss_bwd(dn: DenoiserParams, target, x_start, noise, ts, sqrt_ac, 
 
 @dataclass
 class LossSpan:
-    """Rows [begin, begin + n) of the shared tables go through denoiser `dn` (diffusion_loss_*_spans)."""
+    """Rows [begin, begin + n) of the shared tables go through denoiser `dn` (diffusion_loss_*_spans).
+    drop_p > 0: nn.Dropout(drop_p) in training mode between F.normalize and the first Linear (Model.py:221-224),
+    with the span's rows of the `keep_mask` table given to the call, or a mask drawn in the kernel from its `drop_seed`."""
     dn: DenoiserParams
     begin: int
     n: int
+    drop_p: float = 0.0
 
 
-def _span_tasks(spans: Sequence[LossSpan], n_steps: int, tables: dict):
+def dropout_keep_mask(drop_seed: torch.Tensor, task: int, drop_p: float, n: int) -> torch.Tensor:
+    """The keep mask (uint8 [n, 64]) the loss kernels draw for span number `task` from `drop_seed` (int64[1] on the GPU)."""
+    _vec(drop_seed, "drop_seed", torch.int64, 1)
+    mask = torch.empty((n, DG_D), dtype=torch.uint8, device=drop_seed.device)
+    rc = _lib.load().dg_dropout_keep_mask(drop_seed.data_ptr(), int(task), float(drop_p), n, DG_D, mask.data_ptr(),
+                                          _lib.stream_ptr(drop_seed.device))
+    _lib.check(rc, "dg_dropout_keep_mask")
+    return mask
+
+
+def _check_dropout(spans: Sequence[LossSpan], n: int, keep_mask, drop_seed):
+    if not any(sp.drop_p for sp in spans):
+        return
+    if keep_mask is not None:
+        if not keep_mask.is_cuda or keep_mask.dtype not in (torch.uint8, torch.bool) or tuple(keep_mask.shape) != (n, DG_D) \
+                or not keep_mask.is_contiguous():
+            raise DiffGraphHipError(f"keep_mask: expected a contiguous uint8/bool GPU tensor [{n},{DG_D}]")
+    elif drop_seed is None:
+        raise DiffGraphHipError("dropout needs a keep_mask or a drop_seed")
+    else:
+        _vec(drop_seed, "drop_seed", torch.int64, 1)
+
+
+def _span_tasks(spans: Sequence[LossSpan], n_steps: int, tables: dict, keep_mask=None, drop_seed=None):
     arr = (_lib.LossTask * len(spans))()
     for k, sp in enumerate(spans):
         t = _lib.LossTask()
         t.dn = C.pointer(sp.dn.c)
         t.time_bias = sp.dn.time_bias(n_steps).data_ptr()
         t.n = sp.n
+        t.drop_p = float(sp.drop_p)
+        if sp.drop_p:
+            t.keep_mask = None if keep_mask is None else keep_mask.data_ptr() + sp.begin * DG_D
+            t.drop_seed = None if drop_seed is None else drop_seed.data_ptr()
         for name, (tensor, row_bytes) in tables.items():
             setattr(t, name, None if tensor is None else tensor.data_ptr() + sp.begin * row_bytes)
         arr[k] = t
@@ -395,7 +425,7 @@ def _span_tasks(spans: Sequence[LossSpan], n_steps: int, tables: dict):
 
 
 def diffusion_loss_fwd_spans(spans: Sequence[LossSpan], target, x_start, noise, ts, sqrt_ac, sqrt_1mac, loss_w,
-                             validate: bool = True):
+                             validate: bool = True, keep_mask=None, drop_seed=None):
     """diffusion_loss_fwd over one set of [N,64] tables whose row spans use different denoisers (the user rows
     and the item rows of the recommendation model), in ONE launch.  Returns (row_loss fp64 [N], out [N,64])."""
     n = x_start.shape[0]
@@ -410,12 +440,13 @@ def diffusion_loss_fwd_spans(spans: Sequence[LossSpan], target, x_start, noise, 
         _vec(sqrt_1mac, "sqrt_one_minus_alphas_cumprod", torch.float32, n_steps)
     if sum(sp.n for sp in spans) != n or any(sp.begin < 0 or sp.begin + sp.n > n for sp in spans):
         raise DiffGraphHipError("row spans must tile the tables")
+    _check_dropout(spans, n, keep_mask, drop_seed)
     out = torch.empty_like(x_start)
     row_loss = torch.empty(n, dtype=torch.float64, device=x_start.device)
     rb = DG_D * 4
     arr = _span_tasks(spans, n_steps, {"target": (target, rb), "x_start": (x_start, rb),
                                        "noise": (noise if sqrt_ac is not None else None, rb), "ts": (ts, 8), "out": (out, rb),
-                                       "row_loss": (row_loss, 8)})
+                                       "row_loss": (row_loss, 8)}, keep_mask, drop_seed)
     rc = _lib.load().dg_diffusion_loss_fwd_batched(arr, len(spans), n_steps, _ptr(sqrt_ac), _ptr(sqrt_1mac), loss_w.data_ptr(),
                                                    DG_D, _lib.stream_ptr(x_start.device))
     _lib.check(rc, "dg_diffusion_loss_fwd_batched")
@@ -423,7 +454,7 @@ def diffusion_loss_fwd_spans(spans: Sequence[LossSpan], target, x_start, noise, 
 
 
 def diffusion_loss_bwd_spans(spans: Sequence[LossSpan], target, x_start, noise, ts, sqrt_ac, sqrt_1mac, loss_w, g_row_loss,
-                             g_out, d_target_add=None):
+                             g_out, d_target_add=None, keep_mask=None, drop_seed=None):
     """Backward of diffusion_loss_fwd_spans in ONE launch.  d_target_add ([N,64] or None) is added into d_target.
     Returns (d_x_start, d_target, dout_tot, hid, dpre, xn), all [N,64]."""
     n = x_start.shape[0]
@@ -438,7 +469,8 @@ def diffusion_loss_bwd_spans(spans: Sequence[LossSpan], target, x_start, noise, 
     tables = {"target": (target, rb), "x_start": (x_start, rb), "noise": (noise if sqrt_ac is not None else None, rb),
               "ts": (ts, 8), "g_row_loss": (g_row_loss, 8), "g_out": (g_out, rb), "d_target_add": (d_target_add, rb)}
     tables.update({nm: (o, rb) for nm, o in zip(names, outs)})
-    arr = _span_tasks(spans, n_steps, tables)
+    _check_dropout(spans, n, keep_mask, drop_seed)
+    arr = _span_tasks(spans, n_steps, tables, keep_mask, drop_seed)
     rc = _lib.load().dg_diffusion_loss_bwd_batched(arr, len(spans), n_steps, _ptr(sqrt_ac), _ptr(sqrt_1mac), loss_w.data_ptr(),
                                                    DG_D, _lib.stream_ptr(x_start.device))
     _lib.check(rc, "dg_diffusion_loss_bwd_batched")

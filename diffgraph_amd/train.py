@@ -21,10 +21,12 @@ from .model_rec import DEFAULT_ARGS, HGDM
 from .optim import Adam
 
 
-def training_step(model, opt, ancs, poss, negs, seed: torch.Tensor) -> torch.Tensor:
+def training_step(model, opt, ancs, poss, negs, seed: torch.Tensor, draws: Optional[dict] = None) -> torch.Tensor:
     """One step of Coach.trainEpoch's loop (main.py:120-128): cal_loss, backward, Adam.  `seed` is the float64 device
-    vector [1, 0, 0, 0] = d loss / d (loss, bprLoss, regLoss, diff_loss).  Returns those four values (float64[4])."""
-    res = model.cal_loss_vector(ancs, poss, negs)
+    vector [1, 0, 0, 0] = d loss / d (loss, bprLoss, regLoss, diff_loss).  `draws`: the step's random inputs as
+    keyword arguments of HGDM.cal_loss_vector (ts_u, noise_u, ts_i, noise_i, keep_u, keep_i) when they are not to
+    be drawn inside.  Returns the four values (float64[4])."""
+    res = model.cal_loss_vector(ancs, poss, negs, **(draws or {}))
     opt.zero_grad(set_to_none=True)
     res.backward(seed)                                           # = loss.backward()
     opt.step()
@@ -41,10 +43,14 @@ class Coach:
         self._graphs = {}
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed)
+        self._draws = None
+        self._draw_no = None
 
     # ------------------------------------------------------------------ main.py:102-105
     def prepareModel(self) -> None:
-        self.model = HGDM(self.handler, self.args, device=self.device).eval()   # dropout off: see HGDM.cal_loss
+        # nn.Module's default mode is train(): like the reference's, the model runs its first epoch with the
+        # denoisers' dropout on, and testEpoch() switches it off for good (main.py:144)
+        self.model = HGDM(self.handler, self.args, device=self.device)
         self.opt = Adam(self.model, lr=self.args.lr, weight_decay=0)
         self._sums = torch.zeros(4, dtype=torch.float64, device=self.device)        # Loss, recLoss, regLoss, diffLoss
         self._seed = torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=self.device)   # d loss / d (the four)
@@ -54,25 +60,47 @@ class Coach:
         self._epoch = torch.zeros((self._n_batches, 3, B), dtype=torch.int64, device=self.device)
         self._flat = torch.zeros((3, self._n_batches * B), dtype=torch.int64, device=self.device)
         self._batch_no = torch.zeros(1, dtype=torch.int64, device=self.device)       # advanced by every recorded step
-        self._graphs = {}     # batch size -> recorded step
+        self._graphs = {}     # (batch size, training mode) -> recorded step
+
+    def set_draws(self, ts: torch.Tensor, noise: torch.Tensor, keep: Optional[torch.Tensor] = None) -> None:
+        """Fixes the random inputs of the training steps to come: step k (counted from this call, over epochs) takes
+        timesteps ts[k] (int64 [n_user + n_item]), noise noise[k] ([n_user + n_item, 64]) and, in training mode, the
+        dropout keep mask keep[k] (uint8, same shape) instead of drawing them -- so that two Coaches, or a replayed and
+        an eagerly launched step, can be compared number for number.  The step reads them through a device-side
+        counter: recorded steps stay valid."""
+        dev = self.device
+        self._draws = (ts.to(dev).long().contiguous(), noise.to(dev).float().contiguous(),
+                       None if keep is None else keep.to(dev).to(torch.uint8).contiguous())
+        self._draw_no = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._graphs = {}
 
     def _step(self, ancs, poss, negs) -> None:
-        self._sums += training_step(self.model, self.opt, ancs, poss, negs, self._seed).detach()
+        draws = None
+        if self._draws is not None:
+            ts, noise, keep = (None if t is None else t.index_select(0, self._draw_no)[0] for t in self._draws)
+            self._draw_no.add_(1)
+            nu = self.model.n_user
+            draws = dict(ts_u=ts[:nu], ts_i=ts[nu:], noise_u=noise[:nu], noise_i=noise[nu:], validate=False)
+            if keep is not None:
+                draws.update(keep_u=keep[:nu], keep_i=keep[nu:])
+        self._sums += training_step(self.model, self.opt, ancs, poss, negs, self._seed, draws).detach()
 
     def _snapshot(self):
         o = self.opt
         return ([p.detach().clone() for p in self.model.parameters()], o.exp_avg.clone(), o.exp_avg_sq.clone(), o.state.clone(),
                 {p: {k: v.clone() for k, v in st.items()} for p, st in o.rest.state.items()}, self._sums.clone(),
-                self._batch_no.clone())
+                self._batch_no.clone(), None if self._draw_no is None else self._draw_no.clone())
 
     def _restore(self, snap) -> None:
         """Puts the values back IN PLACE: the recorded graph holds the addresses of these tensors."""
-        params, m, v, state, rest, sums, batch_no = snap
+        params, m, v, state, rest, sums, batch_no, draw_no = snap
         o = self.opt
         with torch.no_grad():
             for p, q in zip(self.model.parameters(), params):
                 p.copy_(q)
             o.exp_avg.copy_(m); o.exp_avg_sq.copy_(v); o.state.copy_(state); self._sums.copy_(sums); self._batch_no.copy_(batch_no)
+            if draw_no is not None:
+                self._draw_no.copy_(draw_no)
             for p, st in o.rest.state.items():      # moments the warm-up steps created start from zero
                 for k, t in st.items():
                     t.copy_(rest[p][k]) if p in rest else t.zero_()
@@ -99,7 +127,7 @@ class Coach:
         with torch.cuda.graph(graph):
             step()
         self._restore(keep)
-        self._graphs[size] = graph
+        self._graphs[(size, self.model.training)] = graph
         return graph
 
     # ------------------------------------------------------------------ main.py:107-136
@@ -116,7 +144,7 @@ class Coach:
             self._epoch.copy_(self._flat.view(3, self._n_batches, B).permute(1, 0, 2))
             for b in range(0, n, B):
                 size = min(B, n - b)
-                graph = self._graphs.get(size) or self._capture(size)
+                graph = self._graphs.get((size, self.model.training)) or self._capture(size)   # a recording holds its mode
                 if b == 0:
                     self._batch_no.zero_()
                 graph.replay()
@@ -130,6 +158,7 @@ class Coach:
 
     # ------------------------------------------------------------------ main.py:138-167
     def testEpoch(self) -> Dict[str, float]:
+        self.model.eval()      # main.py:144 -- and nothing switches back: dropout is on during the first epoch only
         res = evaluate.testEpoch(self.model, self.handler.tst_data, self.args.topk, self.args.tstBat)
         return {"Recall": res["Recall"], "NDCG": res["NDCG"]}
 

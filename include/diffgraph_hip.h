@@ -299,7 +299,21 @@ typedef struct dg_loss_task {
   const double *g_row_loss; /* backward */
   const float *g_out, *d_target_add;
   float *d_x_start, *d_target, *dout_tot, *hid, *dpre, *xn;
+  /* Training-mode dropout of Denoise.forward (nn.Dropout between F.normalize and the first Linear,
+   * DiffGraph-Rec/Model.py:193,221-224; active while the module is in train() mode, i.e. the reference's
+   * first epoch, main.py:144).  drop_p = 0: off.  Otherwise an element is multiplied by 1/(1-drop_p) if kept
+   * and by 0 if dropped; kept = keep_mask[row][col] != 0 when keep_mask (uint8 [n][64]) is given, else a draw
+   * of probability 1 - round(256 drop_p)/256 from a counter-based generator keyed by the DEVICE word
+   * *drop_seed, the task's position in the call and the row -- the backward call redraws the same mask from
+   * the same word; dg_dropout_keep_mask writes it out. */
+  const uint8_t *keep_mask;
+  const int64_t *drop_seed;
+  float drop_p;
 } dg_loss_task;
+
+/* The keep mask (uint8 [n][64], 1 = kept) the loss entry points draw for task number `task` from *drop_seed. */
+int dg_dropout_keep_mask(const int64_t *drop_seed, int32_t task, float drop_p, int64_t n, int32_t d, uint8_t *mask,
+                         void *stream);
 
 int dg_diffusion_loss_fwd_batched(const dg_loss_task *tasks, int32_t n_tasks, int32_t n_steps,
                                   const float *sqrt_ac, const float *sqrt_1mac, const double *loss_w,

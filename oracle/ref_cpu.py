@@ -206,12 +206,17 @@ def time_embedding(timesteps: torch.Tensor, dim: int = 8, dtype=torch.float32) -
     return torch.cat([torch.cos(temp), torch.sin(temp)], dim=-1).to(dtype)
 
 
-def denoise_forward(wts: DenoiseWeights, x: torch.Tensor, timesteps: torch.Tensor, norm: bool = True):
+def denoise_forward(wts: DenoiseWeights, x: torch.Tensor, timesteps: torch.Tensor, norm: bool = True,
+                    keep_mask: Optional[torch.Tensor] = None, drop_p: float = 0.5):
+    """keep_mask ([n, 64], nonzero = kept): the module in training mode with mess_dropout (Model.py:223-224) --
+    nn.Dropout multiplies the kept elements by 1/(1-p) and zeroes the others; the mask is passed in (torch draws it)."""
     dt = x.dtype
     te = time_embedding(timesteps, wts.w_emb.shape[1], dt)
     emb = F.linear(te, wts.w_emb, wts.b_emb)                  # Model.py:220
     if norm:
         x = F.normalize(x)                                    # Model.py:221-222
+    if keep_mask is not None:
+        x = x * (keep_mask != 0).to(dt).div(1.0 - drop_p)     # Model.py:223-224 (the noise tensor of at::dropout)
     h = torch.cat([x, emb], dim=-1)                           # Model.py:225
     h = torch.tanh(F.linear(h, wts.w_in, wts.b_in))           # Model.py:226-228
     return F.linear(h, wts.w_out, wts.b_out)                  # Model.py:229-232 (single out layer: no tanh)
@@ -241,10 +246,10 @@ def p_sample(tab: DiffusionTables, wts: DenoiseWeights, x_start: torch.Tensor, s
 
 # a9: training_losses2 Model.py:348-366
 def training_losses2(tab: DiffusionTables, wts: DenoiseWeights, target: torch.Tensor, x_start: torch.Tensor,
-                     batch: torch.Tensor, ts: torch.Tensor, noise: torch.Tensor):
-    """ts / noise are passed in (the reference draws them at Model.py:352-353)."""
+                     batch: torch.Tensor, ts: torch.Tensor, noise: torch.Tensor, keep_mask: Optional[torch.Tensor] = None):
+    """ts / noise are passed in (the reference draws them at Model.py:352-353); keep_mask: training mode."""
     x_t = q_sample(tab, x_start, ts, noise) if tab.noise_scale != 0 else x_start
-    out = denoise_forward(wts, x_t, ts)
+    out = denoise_forward(wts, x_t, ts, keep_mask=keep_mask)
     mse = ((target - out) ** 2).mean(dim=1)
     loss = tab.loss_weight(ts) * mse                          # fp64 weight * fp32 mse -> fp64
     return loss[batch], out

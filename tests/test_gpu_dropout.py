@@ -1,0 +1,155 @@
+"""Training-mode dropout inside training_losses2 (nn.Dropout(0.5) between F.normalize and the first Linear of
+Denoise, DiffGraph-Rec/Model.py:193,221-224; DiffGraph_NC/Model.py:262-265), fused into the loss kernels.
+Golden values come from the reference's own cal_loss in train() mode with the keep masks torch drew recorded
+(tools/make_golden.py rec_train / nc_train)."""
+import numpy as np
+import pytest
+import torch
+
+import diffgraph_amd as dg
+from diffgraph_amd import data as dgdata, ops
+from tests.helpers import REC_TABLE, assert_rows_close, load, tiny_fixture
+from tests.test_gpu_parity import DEV, dev, rec_model, T
+
+pytestmark = pytest.mark.gpu
+NAMES = ("w_emb", "b_emb", "w_in", "b_in", "w_out", "b_out")
+
+
+def _grads(dn):
+    return {"w_emb": dn.emb_layer.weight.grad, "b_emb": dn.emb_layer.bias.grad, "w_in": dn.in_layers[0].weight.grad,
+            "b_in": dn.in_layers[0].bias.grad, "w_out": dn.out_layers[0].weight.grad, "b_out": dn.out_layers[0].bias.grad}
+
+
+def test_training_losses2_train_mode_golden():
+    fx, nu, *_ = tiny_fixture()
+    tr = load("rec_tiny_train.npz")
+    gd = dg.GaussianDiffusion(**REC_TABLE)
+    m = rec_model(dgdata.rec_workload("tiny"), fx).train()
+    with torch.no_grad():
+        loss, out = gd.training_losses2(m.usr_denoiser, dev(fx["fwd_tu"]), dev(fx["fwd_hu"]), dev(fx["tl_batch"]),
+                                        ts=dev(tr["tl_ts"]), noise=dev(tr["tl_noise"]), keep_mask=dev(tr["tl_keep"]))
+    assert_rows_close(out, tr["tl_out"], what="training_losses2 out (train mode)")
+    np.testing.assert_allclose(loss.cpu().numpy(), tr["tl_loss"], rtol=1e-5)
+    # and the mask matters: eval mode gives other numbers
+    m.eval()
+    with torch.no_grad():
+        _, out_eval = gd.training_losses2(m.usr_denoiser, dev(fx["fwd_tu"]), dev(fx["fwd_hu"]), dev(fx["tl_batch"]),
+                                          ts=dev(tr["tl_ts"]), noise=dev(tr["tl_noise"]))
+    assert float((out_eval.cpu() - T(tr["tl_out"])).abs().max()) > 1e-3
+
+
+def test_rec_cal_loss_train_mode_golden():
+    """cal_loss + backward in train() mode -- the reference's first epoch -- against the reference's own numbers:
+    the four losses, the gradients of both embedding tables and of all twelve denoiser parameters."""
+    fx, nu, ni, *_ = tiny_fixture()
+    tr = load("rec_tiny_train.npz")
+    m = rec_model(dgdata.rec_workload("tiny"), fx).train()
+    m.set_embeddings(dev(fx["user_emb"]), dev(fx["item_emb"]))
+    from types import SimpleNamespace
+    m.args = SimpleNamespace(**{**vars(m.args), "batch": int(fx["cl_batch_div"][0]), "reg": float(fx["cl_batch_div"][1])})
+    loss, bpr, reg, diff = m.cal_loss(dev(fx["cl_ancs"]), dev(fx["cl_poss"]), dev(fx["cl_negs"]), dev(tr["ts_u"]),
+                                      dev(tr["noise_u"]), dev(tr["ts_i"]), dev(tr["noise_i"]), dev(tr["keep_u"]), dev(tr["keep_i"]))
+    np.testing.assert_allclose([float(v.detach()) for v in (loss, bpr, reg, diff)], tr["losses"], rtol=1e-5)
+    loss.backward()
+    g = m.embedding_table.grad
+    assert_rows_close(g[:nu], tr["grad_user"], rtol=1e-4, what="grad user_emb")
+    assert_rows_close(g[nu:], tr["grad_item"], rtol=1e-4, what="grad item_emb")
+    for pre, dn in (("usr_", m.usr_denoiser), ("item_", m.item_denoiser)):
+        for nm, gv in _grads(dn).items():
+            want = tr["grad_" + pre + nm]
+            np.testing.assert_allclose(gv.cpu().numpy(), want, rtol=0, atol=1e-4 * np.abs(want).max(), err_msg="grad " + pre + nm)
+
+
+def test_nc_cal_loss_train_mode_golden():
+    """One NC training step with the denoiser's dropout on, as every step of the reference's NC program runs
+    (it never calls eval()): losses and all ten parameter gradients, as-coded graphs (3 x APA)."""
+    from tests.test_oracle_golden import _dblp_graphs
+    fx, tr = load("nc_dblp.npz"), load("nc_dblp_train.npz")
+    NA, apa, apcpa, aptpa, features = _dblp_graphs()
+    adjs = [dg.CSRGraph.from_scipy(apa) for _ in range(3)]
+    model = dg.nc.HGDM(features.shape[1]).train()
+    dn = model.user_denoise_model
+    with torch.no_grad():
+        model.transform_layer.weight.copy_(dev(fx["w_t"])); model.transform_layer.bias.copy_(dev(fx["b_t"]))
+        model.dense.weight.copy_(dev(fx["w_dense"])); model.dense.bias.copy_(dev(fx["b_dense"]))
+        dn.emb_layer.weight.copy_(dev(fx["dn_w_emb"])); dn.emb_layer.bias.copy_(dev(fx["dn_b_emb"]))
+        dn.in_layers[0].weight.copy_(dev(fx["dn_w_in"])); dn.in_layers[0].bias.copy_(dev(fx["dn_b_in"]))
+        dn.out_layers[0].weight.copy_(dev(fx["dn_w_out"])); dn.out_layers[0].bias.copy_(dev(fx["dn_b_out"]))
+    onehot = torch.zeros(NA, 4)
+    onehot[torch.arange(NA), T(load("dblp_graph.npz")["labels"])] = 1.0
+    nll, diff = model.cal_loss(dev(fx["cl_ancs"]), dev(onehot), adjs, dev(features), dev(tr["ts"]), dev(tr["noise"]),
+                               dev(tr["keep"]))
+    np.testing.assert_allclose([float(nll.detach()), float(diff.detach())], tr["losses"], rtol=2e-5)
+    (nll + diff).backward()
+    got = dict(model.named_parameters())
+    checked = 0
+    for nm, prm in got.items():
+        key = "grad_" + nm.replace(".", "_")
+        if key not in tr.files:
+            continue
+        want = tr[key]
+        assert prm.grad is not None, nm
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), want, rtol=0, atol=1e-4 * np.abs(want).max(), err_msg="grad " + nm)
+        checked += 1
+    assert checked == 10
+
+
+def test_mask_drawn_in_the_kernel_equals_the_mask_supplied():
+    """Without a caller's mask the kernels draw one from a seed word on the device (counter-based generator keyed by
+    seed, span and row).  dg_dropout_keep_mask writes that mask out: feeding it back as keep_mask gives the same
+    bits, forward and backward -- so the backward redraws exactly what the forward used -- and the draw has the
+    statistics of Dropout(0.5)."""
+    gen = torch.Generator().manual_seed(5)
+    n_u, n_i, n_steps = 777, 333, 200
+    n = n_u + n_i
+    gd = dg.GaussianDiffusion(**REC_TABLE)
+    dns = [dg.Denoise([64, 64], [64, 64], 8, norm=True).to(DEV) for _ in range(2)]
+    spans = [ops.LossSpan(dns[0].params(True), 0, n_u, 0.5), ops.LossSpan(dns[1].params(True), n_u, n_i, 0.5)]
+    ops.refresh_time_bias([sp.dn for sp in spans], n_steps)
+    target, x0, noise = (dev(torch.randn(n, 64, generator=gen)) for _ in range(3))
+    ts = dev(torch.randint(0, n_steps, (n,), generator=gen))
+    sa, sb = gd._dev("sqrt_alphas_cumprod", DEV), gd._dev("sqrt_one_minus_alphas_cumprod", DEV)
+    lw = gd._dev("loss_weight", DEV, torch.float64)
+    g_row = dev(torch.rand(n, generator=gen).double())
+    g_out = dev(torch.randn(n, 64, generator=gen))
+    seed = torch.tensor([123456789012345], dtype=torch.int64, device=DEV)
+    rl_a, out_a = ops.diffusion_loss_fwd_spans(spans, target, x0, noise, ts, sa, sb, lw, drop_seed=seed)
+    bwd_a = ops.diffusion_loss_bwd_spans(spans, target, x0, noise, ts, sa, sb, lw, g_row, g_out, drop_seed=seed)
+    mask = torch.cat([ops.dropout_keep_mask(seed, 0, 0.5, n_u), ops.dropout_keep_mask(seed, 1, 0.5, n_i)])
+    rl_b, out_b = ops.diffusion_loss_fwd_spans(spans, target, x0, noise, ts, sa, sb, lw, keep_mask=mask)
+    bwd_b = ops.diffusion_loss_bwd_spans(spans, target, x0, noise, ts, sa, sb, lw, g_row, g_out, keep_mask=mask)
+    assert torch.equal(rl_a, rl_b) and torch.equal(out_a, out_b)
+    for a, b in zip(bwd_a, bwd_b):
+        assert torch.equal(a, b)
+    m = mask.float()
+    assert set(mask.unique().tolist()) == {0, 1}
+    assert abs(float(m.mean()) - 0.5) < 0.01
+    assert float(m.mean(0).min()) > 0.4 and float(m.mean(0).max()) < 0.6           # every column
+    assert abs(float((m[:-1] * m[1:]).mean()) - 0.25) < 0.01                          # neighbouring rows independent
+    assert not torch.equal(ops.dropout_keep_mask(seed, 0, 0.5, n_i), ops.dropout_keep_mask(seed, 1, 0.5, n_i))
+    assert not torch.equal(ops.dropout_keep_mask(seed, 0, 0.5, n_i), ops.dropout_keep_mask(seed + 1, 0, 0.5, n_i))
+    # the dropped inputs reach the first Linear as zeros and the kept ones doubled: xn table of the backward
+    xn = bwd_a[5]
+    unit = torch.nn.functional.normalize(sa[ts][:, None] * x0 + sb[ts][:, None] * noise)
+    assert_rows_close(xn, unit * m * 2.0, what="xn after dropout")
+    # eval-mode call (drop_p = 0) ignores seed and mask
+    plain = [ops.LossSpan(sp.dn, sp.begin, sp.n) for sp in spans]
+    rl_c, _ = ops.diffusion_loss_fwd_spans(plain, target, x0, noise, ts, sa, sb, lw)
+    assert not torch.equal(rl_c, rl_a)
+    with pytest.raises(dg.DiffGraphHipError):
+        ops.diffusion_loss_fwd_spans(spans, target, x0, noise, ts, sa, sb, lw)      # dropout on, neither mask nor seed
+
+
+def test_model_in_train_mode_draws_fresh_masks():
+    fx, nu, ni, *_ = tiny_fixture()
+    m = rec_model(dgdata.rec_workload("tiny"), fx).train()
+    m.set_embeddings(dev(fx["user_emb"]), dev(fx["item_emb"]))
+    args = (dev(fx["cl_ancs"]), dev(fx["cl_poss"]), dev(fx["cl_negs"]), dev(fx["cl_ts_u"]), dev(fx["cl_noise_u"]),
+            dev(fx["cl_ts_i"]), dev(fx["cl_noise_i"]))
+    with torch.no_grad():
+        a, b = m.cal_loss_vector(*args), m.cal_loss_vector(*args)
+        m.eval()
+        c, d = m.cal_loss_vector(*args), m.cal_loss_vector(*args)
+    assert torch.isfinite(a).all() and not torch.equal(a, b)     # two draws
+    assert torch.equal(c, d)                                     # no dropout: deterministic
+    np.testing.assert_allclose(c.cpu().numpy(), fx["cl_losses"], rtol=1e-5)

@@ -134,6 +134,43 @@ def test_cal_loss_and_gradients():
             assert_rows_close(getattr(w, nm).grad, fx["cl_grad_" + pre + nm], rtol=1e-4, what="grad " + pre + nm)
 
 
+def test_training_mode_dropout_losses_and_gradients():
+    """The reference's first epoch (train() mode): Dropout(0.5) after F.normalize in both denoisers.  The oracle with
+    the recorded keep masks reproduces training_losses2, cal_loss and the gradients of the reference's own run."""
+    fx, nu, ni, target, behs = tiny_fixture()
+    tr = load("rec_tiny_train.npz")
+    tab = O.DiffusionTables(**REC_TABLE)
+    loss, out = O.training_losses2(tab, weights_from(fx, "usr_"), T(fx["fwd_tu"]), T(fx["fwd_hu"]), T(fx["tl_batch"]),
+                                   T(tr["tl_ts"]), T(tr["tl_noise"]), T(tr["tl_keep"]))
+    assert_rows_close(out, tr["tl_out"], what="tl out (train mode)")
+    np.testing.assert_allclose(loss.numpy(), tr["tl_loss"], rtol=1e-5)
+    ue = T(fx["user_emb"]).clone().requires_grad_(True)
+    ie = T(fx["item_emb"]).clone().requires_grad_(True)
+    wu, wi = weights_from(fx, "usr_"), weights_from(fx, "item_")
+    for w in (wu, wi):
+        for nm in ("w_emb", "b_emb", "w_in", "b_in", "w_out", "b_out"):
+            setattr(w, nm, getattr(w, nm).clone().requires_grad_(True))
+    ancs, poss, negs = T(fx["cl_ancs"]), T(fx["cl_poss"]), T(fx["cl_negs"])
+    batch, reg = fx["cl_batch_div"]
+    tu, ti, hu, hi = O.rec_forward(target, behs, ue, ie, 2)
+    lu, du = O.training_losses2(tab, wu, tu, hu, ancs, T(tr["ts_u"]), T(tr["noise_u"]), T(tr["keep_u"]))
+    li, di = O.training_losses2(tab, wi, ti, hi, poss, T(tr["ts_i"]), T(tr["noise_i"]), T(tr["keep_i"]))
+    diff = lu.mean() + li.mean()
+    usr, itm = tu + du, ti + di
+    a, p, n = usr[ancs], itm[poss], itm[negs]
+    score = (a * p).sum(-1) - (a * n).sum(-1)
+    bpr = -score.sigmoid().log().sum() / batch
+    regl = ((torch.norm(a) ** 2 + torch.norm(p) ** 2 + torch.norm(n) ** 2) * reg) / batch
+    loss = bpr + regl + diff
+    np.testing.assert_allclose([loss.item(), bpr.item(), regl.item(), diff.item()], tr["losses"], rtol=1e-6)
+    loss.backward()
+    assert_rows_close(ue.grad, tr["grad_user"], rtol=1e-4, what="grad user_emb")
+    assert_rows_close(ie.grad, tr["grad_item"], rtol=1e-4, what="grad item_emb")
+    for pre, w in (("usr_", wu), ("item_", wi)):
+        for nm in ("w_emb", "b_emb", "w_in", "b_in", "w_out", "b_out"):
+            assert_rows_close(getattr(w, nm).grad, tr["grad_" + pre + nm], rtol=1e-4, what="grad " + pre + nm)
+
+
 def _dblp_graphs():
     import scipy.sparse as sp
     g = load("dblp_graph.npz")

@@ -93,10 +93,20 @@ class Recorder:
     """Captures the tensors torch.randint / torch.randn_like hand to the reference."""
 
     def __init__(self):
-        self.randint, self.randn = [], []
+        self.randint, self.randn, self.dropout = [], [], []
 
     def __enter__(self):
         self._ri, self._rn = torch.randint, torch.randn_like
+        self._dr = torch.nn.functional.dropout
+
+        def dr(input, p=0.5, training=True, inplace=False):
+            # torch's own dropout; the keep mask is read off its output (no input element is exactly zero)
+            out = self._dr(input, p, training, False)
+            if training and p > 0:
+                assert bool((input != 0).all())
+                self.dropout.append((out != 0).clone())
+            return out
+        torch.nn.functional.dropout = dr
 
         def ri(*a, **k):
             out = self._ri(*a, **k)
@@ -113,6 +123,7 @@ class Recorder:
 
     def __exit__(self, *exc):
         torch.randint, torch.randn_like = self._ri, self._rn
+        torch.nn.functional.dropout = self._dr
 
 
 # --------------------------------------------------------------------------------------
@@ -253,6 +264,50 @@ def gen_rec():
     print("rec_retail_rocket.npz:", len(fx), "arrays")
 
 
+def gen_rec_train():
+    """cal_loss + backward of the tiny Rec model in TRAINING mode -- what the reference's first epoch runs
+    (main.py:144 is its only eval()): nn.Dropout(0.5) between F.normalize and the first Linear of both denoisers
+    (Model.py:193,221-224).  Same model and inputs as the eval-mode `cl_*` entries of rec_tiny.npz; the two keep
+    masks torch drew are recorded beside the timesteps and the noise."""
+    Model = import_reference("DiffGraph-Rec")
+    from diffgraph_amd import data as dgdata
+    wl = dgdata.rec_workload("tiny")
+    model, handler = build_rec_model(Model, wl, seed=7)
+    nu, ni = wl.n_user, wl.n_item
+    ref = np.load(os.path.join(OUT, "rec_tiny.npz"))
+    for k, v in denoiser_state(model.usr_denoiser, "usr_").items():
+        assert np.array_equal(v, ref[k]), k          # the same model as rec_tiny.npz describes
+    model.train()
+    ancs, poss, negs = (torch.from_numpy(ref[k]) for k in ("cl_ancs", "cl_poss", "cl_negs"))
+    model.zero_grad()
+    with Recorder() as rec:
+        torch.manual_seed(37)
+        loss, bpr, reg, diff = model.cal_loss(ancs, poss, negs)
+    loss.backward()
+    fx = {"ts_u": np64(rec.randint[0]), "ts_i": np64(rec.randint[1]), "noise_u": np64(rec.randn[0]),
+          "noise_i": np64(rec.randn[1]), "keep_u": np64(rec.dropout[0]).astype(np.uint8),
+          "keep_i": np64(rec.dropout[1]).astype(np.uint8),
+          "losses": np.array([loss.item(), bpr.item(), reg.item(), diff.item()], dtype=np.float64)}
+    assert fx["keep_u"].shape == (nu, 64) and fx["keep_i"].shape == (ni, 64) and len(rec.dropout) == 2
+    ue, ie = model.embedding_dict["user_emb"], model.embedding_dict["item_emb"]
+    fx["grad_user"], fx["grad_item"] = np64(ue.grad), np64(ie.grad)
+    for pre, dn in (("usr_", model.usr_denoiser), ("item_", model.item_denoiser)):
+        for nm, q in (("w_emb", dn.emb_layer.weight), ("b_emb", dn.emb_layer.bias), ("w_in", dn.in_layers[0].weight),
+                      ("b_in", dn.in_layers[0].bias), ("w_out", dn.out_layers[0].weight), ("b_out", dn.out_layers[0].bias)):
+            fx["grad_" + pre + nm] = np64(q.grad)
+    # training_losses2 alone, in training mode (forward values)
+    with torch.no_grad():
+        tu, ti, hu, hi = model.forward()
+        batch = torch.from_numpy(ref["tl_batch"])
+        with Recorder() as rec:
+            torch.manual_seed(41)
+            l2, out = model.diffusion_process.training_losses2(model.usr_denoiser, tu, hu, batch)
+        fx["tl_ts"], fx["tl_noise"], fx["tl_keep"] = np64(rec.randint[0]), np64(rec.randn[0]), np64(rec.dropout[0]).astype(np.uint8)
+        fx["tl_loss"], fx["tl_out"] = np64(l2), np64(out)
+    np.savez_compressed(os.path.join(OUT, "rec_tiny_train.npz"), **fx)
+    print("rec_tiny_train.npz:", len(fx), "arrays; keep fractions", fx["keep_u"].mean(), fx["keep_i"].mean())
+
+
 # --------------------------------------------------------------------------------------
 # NC (DBLP)
 # --------------------------------------------------------------------------------------
@@ -352,6 +407,47 @@ def gen_nc():
             fx["tr_grad_" + nm.replace(".", "_")] = np64(p.grad)
     np.savez_compressed(os.path.join(OUT, "nc_dblp.npz"), **fx)
     print("nc_dblp.npz:", len(fx), "arrays")
+
+
+def gen_nc_train():
+    """One NC training step in TRAINING mode on the as-coded graphs (3 x APA).  The reference's NC program never
+    calls eval(), so every one of its training steps runs the denoiser's Dropout(0.5) (DiffGraph_NC/Model.py:262-265;
+    main.py:378-386: loss = nll + diff_loss; backward).  Same model as nc_dblp.npz; the keep mask is recorded."""
+    Model = import_reference("DiffGraph_NC")
+    import scipy.sparse as sp
+    feats, edges, labels = load_dblp()
+    NA = feats.shape[0]
+    ap = edges["ap"]
+    NP = max(ap[:, 1].max(), edges["pa"][:, 0].max()) + 1
+    rowsum = np.array(feats.sum(1)).flatten()
+    r_inv = np.power(rowsum, -1).flatten()
+    r_inv[np.isinf(r_inv)] = 0.0
+    features = torch.FloatTensor(np.asarray(sp.diags(r_inv).dot(feats).todense()))
+    A_P = sp.coo_matrix((np.ones(len(ap)), (ap[:, 0], ap[:, 1])), shape=(NA, NP)).tocsr()
+    apa = ((A_P @ A_P.T) != 0).astype(np.float32).tocoo()
+    adjs = [FakeGraph(apa.row, apa.col, NA) for _ in range(3)]
+    torch.manual_seed(23)
+    model = Model.HGDM(features.shape[1])
+    ref = np.load(os.path.join(OUT, "nc_dblp.npz"))
+    assert np.array_equal(np64(model.transform_layer.weight), ref["w_t"])      # the model nc_dblp.npz describes
+    assert np.array_equal(np64(model.user_denoise_model.in_layers[0].weight), ref["dn_w_in"])
+    model.train()
+    onehot = torch.zeros(NA, 4)
+    onehot[torch.arange(NA), torch.from_numpy(labels).long()] = 1.0
+    ancs = torch.from_numpy(ref["cl_ancs"])
+    model.zero_grad()
+    with Recorder() as rec:
+        torch.manual_seed(43)
+        nll, diff = model.cal_loss(ancs, onehot, adjs, features)
+    (nll + diff).backward()
+    fx = {"ts": np64(rec.randint[0]), "noise": np64(rec.randn[0]), "keep": np64(rec.dropout[0]).astype(np.uint8),
+          "losses": np.array([nll.item(), diff.item()], dtype=np.float64)}
+    assert len(rec.dropout) == 1 and fx["keep"].shape == (NA, 64)
+    for nm, q in model.named_parameters():
+        if q.grad is not None:
+            fx["grad_" + nm.replace(".", "_")] = np64(q.grad)
+    np.savez_compressed(os.path.join(OUT, "nc_dblp_train.npz"), **fx)
+    print("nc_dblp_train.npz:", len(fx), "arrays; keep fraction", fx["keep"].mean())
 
 
 # --------------------------------------------------------------------------------------
@@ -455,9 +551,10 @@ def gen_metapath():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "nc", "eval", "metapath"]
+    which = sys.argv[1:] or ["rec", "rec_train", "nc", "nc_train", "eval", "metapath"]
     if len(which) == 1:
-        {"rec": gen_rec, "nc": gen_nc, "eval": gen_eval, "metapath": gen_metapath}[which[0]]()
+        {"rec": gen_rec, "rec_train": gen_rec_train, "nc": gen_nc, "nc_train": gen_nc_train, "eval": gen_eval,
+         "metapath": gen_metapath}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
             subprocess.run([sys.executable, os.path.abspath(__file__), w], check=True)
