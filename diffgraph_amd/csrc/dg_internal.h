@@ -24,6 +24,13 @@
 #define DG_WIN_HDR 2           // dwords of per-slot entry-dword counts at the head of a (window, group) block
 #define DG_WIN_ENT_DWORDS 4096 // LDS room for one window's entry blocks (16 KiB)
 #define DG_WIN_MAX_BLOCKS 256
+#define DG_DENSE_MIN_DENSITY 0.10  // above it the bitmap contraction beats gathering 256 B per edge through L2
+#define DG_DENSE_MIN_NODES 256
+// dense_rows_kernel: 32-row tiles (one per wavefront) that share the table rows a workgroup stages, and the number of
+// workgroups a graph is cut into (about one per CU, so that one dense graph alone fills the chip)
+#define DG_DENSE_TILES_PER_BLOCK 4
+#define DG_DENSE_BLOCKS_PER_GRAPH 256
+#define DG_DENSE_MAX_NODES 32768  // bitmap of n^2 / 8 bytes: 128 MiB at the limit
 
 // Records a printf-style message retrievable through dg_last_error(); returns `code`.
 int dg_fail(int code, const char *fmt, ...);
@@ -75,6 +82,14 @@ struct dg_csr {
   uint32_t *wblocks = nullptr, *woff = nullptr;
   int32_t *witems = nullptr;
   int32_t n_windows = 0, n_parts = 0;
+  // Dense graphs (at least DG_DENSE_MIN_DENSITY of all node pairs are edges, no repeated edge): the adjacency as
+  // a bitmap, contracted with the table on the fp32 matrix cores by dense_rows_kernel instead of gathered row by
+  // row.  dense_bits[(tile * dense_chunks + c) * 32 + i] holds columns [64 c, 64 c + 64) of row 32 tile + i
+  // (bit b = column 64 c + b).  The columns are cut into dense_splits ranges of dense_cps chunks; a wavefront sums
+  // one (32-row tile, range) into slab rows row * dense_splits + range, and hub_reduce_kernel adds a row's ranges
+  // in order (hub_desc lists every node).  No row of such a graph is in the other classes.
+  uint64_t *dense_bits = nullptr;
+  int32_t dense_splits = 0, dense_chunks = 0, dense_cps = 0, dense_tiles = 0;
 };
 
 struct dg_graph {
@@ -87,6 +102,7 @@ struct dg_graph {
   dg_csr fwd;                 // rows = destinations, columns = sources
   dg_csr bwd;                 // rows = sources, columns = destinations (aliases fwd when symmetric)
   float *slab = nullptr;      // [max(fwd.n_seg,bwd.n_seg)][64] partial sums of hub-row segments
+  float *dense_x = nullptr;   // [n][64], dense graphs only: the table times the gathered node's norm, when the caller's is not
   int device = 0;
 };
 
@@ -122,6 +138,10 @@ struct dg_task_dev {
   const float *fin_partials;  // dg_gcn_partial_finalize: partial sums [n_parts][stride rows][64] ...
   int64_t fin_stride;         // ... rows between parts
   int32_t fin_parts, fin_row_begin, fin_rows;  // ... for rows [fin_row_begin, fin_row_begin + fin_rows)
+  const uint64_t *dense_bits;   // see dg_csr
+  float *dense_x;
+  int32_t dense_splits, dense_chunks, dense_cps, dense_tiles;
+  int32_t dense_blk_begin;      // first block of this task in the dense_rows_kernel launch
   int32_t blk_begin;      // first block of this task in the main launch
   int32_t hub_blk_begin;  // first block of this task in the hub-row reduce launch
 };

@@ -34,6 +34,8 @@ constexpr int kHead = 13;  // neighbour ids carried in a group row's 16-word hea
 constexpr int kGroupPiece = 32;  // pieces of cut rows up to this long are summed by one 16-lane group, longer ones by a wavefront
 
 struct HostCsr {
+  std::vector<uint64_t> dense_bits;
+  int32_t dense_splits = 0, dense_chunks = 0, dense_cps = 0, dense_tiles = 0;
   std::vector<int32_t> rowptr, colidx, row_order, head, wave_desc, hub_desc, seg_desc, gseg_desc;
   std::vector<float> colscale, head_scale;
   std::vector<uint32_t> lhead, wblocks, woff;
@@ -184,11 +186,45 @@ bool build_windows(int32_t n, const std::vector<int32_t> &deg, HostCsr &c) {
   return true;
 }
 
+// Dense graphs: the bitmap schedule of dg_csr::dense_bits.  Returns false (and leaves c alone) when the graph does
+// not qualify: too sparse, too small or large, or an edge given more than once (a bit cannot count).
+bool build_dense(int32_t n, HostCsr &c) {
+  const int64_t nnz = (int64_t)c.colidx.size();
+  if (n < DG_DENSE_MIN_NODES || n > DG_DENSE_MAX_NODES || (double)nnz < DG_DENSE_MIN_DENSITY * (double)n * (double)n) return false;
+  for (int32_t r = 0; r < n; ++r)
+    for (int32_t p = c.rowptr[r] + 1; p < c.rowptr[r + 1]; ++p)
+      if (c.colidx[p] == c.colidx[p - 1]) return false;
+  const int32_t tiles = (n + 31) / 32, chunks = (n + 63) / 64;
+  // (tile group, range) workgroups: DG_DENSE_BLOCKS_PER_GRAPH per graph
+  const int32_t groups = (tiles + DG_DENSE_TILES_PER_BLOCK - 1) / DG_DENSE_TILES_PER_BLOCK;
+  int32_t splits = std::max(1, std::min(chunks, (DG_DENSE_BLOCKS_PER_GRAPH + groups - 1) / groups));
+  const int32_t cps = (chunks + splits - 1) / splits;
+  splits = (chunks + cps - 1) / cps;
+  c.dense_tiles = tiles; c.dense_chunks = chunks; c.dense_cps = cps; c.dense_splits = splits;
+  c.dense_bits.assign((size_t)groups * DG_DENSE_TILES_PER_BLOCK * chunks * 32, 0);   // whole tile groups
+  for (int32_t r = 0; r < n; ++r)
+    for (int32_t p = c.rowptr[r]; p < c.rowptr[r + 1]; ++p) {
+      const int32_t col = c.colidx[p];
+      c.dense_bits[((size_t)(r >> 5) * chunks + (col >> 6)) * 32 + (r & 31)] |= (uint64_t)1 << (col & 63);
+    }
+  c.hub_desc.clear();
+  for (int32_t r = 0; r < n; ++r) c.hub_desc.insert(c.hub_desc.end(), {r, r * splits, (r + 1) * splits, 0});
+  c.n_hub = n; c.n_seg = n * splits;
+  c.n_wave = c.n_group = c.n_slots = c.slot_begin = c.n_seg_slots = c.n_gseg_slots = 0;
+  c.lds_split = 0; c.n_windows = c.n_parts = 0;
+  c.row_order.clear(); c.seg_desc.clear(); c.gseg_desc.clear(); c.wave_desc.clear(); c.head.clear(); c.head_scale.clear();
+  c.lhead.clear(); c.wblocks.clear(); c.woff.clear(); c.witems.clear();
+  return true;
+}
+
 // Two row classes: group rows (in-degree <= group_max: summed whole by one 16-lane group, in node
 // order) and cut rows (longer: summed in pieces through the slab).  row_order lists cut rows, then
 // group rows, each by falling degree.  Rows below c.lds_split (if set) are left to lds_rows_kernel
 // and appear in no class.
 void build_schedule(int32_t n, int32_t group_max, int32_t seg_len, HostCsr &c, const std::vector<char> *owned = nullptr) {
+  c.dense_bits.clear();
+  c.dense_splits = c.dense_chunks = c.dense_cps = c.dense_tiles = 0;
+  if (!owned && build_dense(n, c)) return;
   std::vector<int32_t> deg(n);
   for (int32_t i = 0; i < n; ++i) deg[i] = c.rowptr[i + 1] - c.rowptr[i];
   c.lds_split = 0;
@@ -362,6 +398,8 @@ hipError_t upload_csr(const HostCsr &h, dg_csr &d) {
   if ((e = upload(h.wblocks, &d.wblocks)) != hipSuccess) return e;
   if ((e = upload(h.woff, &d.woff)) != hipSuccess) return e;
   if ((e = upload(h.witems, &d.witems)) != hipSuccess) return e;
+  if ((e = upload(h.dense_bits, &d.dense_bits)) != hipSuccess) return e;
+  d.dense_splits = h.dense_splits; d.dense_chunks = h.dense_chunks; d.dense_cps = h.dense_cps; d.dense_tiles = h.dense_tiles;
   d.n_windows = h.n_windows; d.n_parts = h.n_parts;
   d.n_hub = h.n_hub; d.n_wave = h.n_wave; d.n_group = h.n_group; d.n_seg = h.n_seg;
   d.lds_split = h.lds_split; d.n_slots = h.n_slots; d.slot_begin = h.slot_begin; d.n_seg_slots = h.n_seg_slots; d.n_gseg_slots = h.n_gseg_slots;
@@ -372,7 +410,7 @@ void free_csr(dg_csr &d) {
   (void)hipFree(d.rowptr); (void)hipFree(d.colidx); (void)hipFree(d.colscale); (void)hipFree(d.row_order);
   (void)hipFree(d.head); (void)hipFree(d.head_scale); (void)hipFree(d.wave_desc); (void)hipFree(d.hub_desc);
   (void)hipFree(d.seg_desc); (void)hipFree(d.gseg_desc); (void)hipFree(d.lhead);
-  (void)hipFree(d.wblocks); (void)hipFree(d.woff); (void)hipFree(d.witems);
+  (void)hipFree(d.wblocks); (void)hipFree(d.woff); (void)hipFree(d.witems); (void)hipFree(d.dense_bits);
   d = dg_csr();
 }
 
@@ -453,6 +491,8 @@ extern "C" int dg_graph_create_ex(int32_t n, int64_t nnz, const int32_t *src, co
     segs = std::max(segs, (size_t)std::max(g->fwd.n_parts, g->bwd.n_parts) * DG_WIN_MAX_BLOCKS);
     e = hipMalloc((void **)&g->slab, std::max<size_t>(segs, 1) * DG_D * sizeof(float));
   }
+  if (e == hipSuccess && (g->fwd.dense_splits > 0 || g->bwd.dense_splits > 0))
+    e = hipMalloc((void **)&g->dense_x, (size_t)n * DG_D * sizeof(float));
   if (e != hipSuccess) {
     dg_graph_destroy(g);
     return dg_fail((int)e, "dg_graph_create: device allocation/copy failed: %s", hipGetErrorString(e));
@@ -465,7 +505,7 @@ extern "C" void dg_graph_destroy(dg_graph *g) {
   if (!g) return;
   if (!g->symmetric) free_csr(g->bwd);
   free_csr(g->fwd);
-  (void)hipFree(g->dinv_src); (void)hipFree(g->dinv_dst); (void)hipFree(g->slab);
+  (void)hipFree(g->dinv_src); (void)hipFree(g->dinv_dst); (void)hipFree(g->slab); (void)hipFree(g->dense_x);
   delete g;
 }
 
@@ -477,13 +517,16 @@ extern "C" int dg_graph_export(const dg_graph *g, int which, void *dst, size_t b
   if (!g || !dst) return dg_fail(DG_ERR_ARG, "dg_graph_export: NULL argument");
   const void *src = nullptr;
   size_t need = 0;
-  int32_t counts[5] = {g->fwd.n_hub, g->fwd.n_wave, g->fwd.n_group, g->fwd.n_seg, g->fwd.lds_split};
+  int32_t counts[6] = {g->fwd.n_hub, g->fwd.n_wave, g->fwd.n_group, g->fwd.n_seg, g->fwd.lds_split, g->fwd.dense_splits};
   switch (which) {
     case 0: src = g->fwd.rowptr; need = ((size_t)g->n + 1) * 4; break;
     case 1: src = g->fwd.colidx; need = (size_t)g->nnz * 4; break;
     case 2: src = g->dinv_src; need = (size_t)g->n * 4; break;
     case 3: src = g->dinv_dst; need = (size_t)g->n * 4; break;
-    case 4: src = g->fwd.row_order; need = (size_t)(g->fwd.n_hub + g->fwd.n_wave + g->fwd.n_group) * 4; break;
+    case 4:
+      src = g->fwd.row_order;
+      need = g->fwd.dense_splits > 0 ? 0 : (size_t)(g->fwd.n_hub + g->fwd.n_wave + g->fwd.n_group) * 4;
+      break;
     case 5:
       if (bytes < sizeof(counts)) return dg_fail(DG_ERR_SIZE, "dg_graph_export: buffer too small");
       memcpy(dst, counts, sizeof(counts));

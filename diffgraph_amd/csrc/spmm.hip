@@ -33,6 +33,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -538,6 +539,102 @@ __global__ __launch_bounds__(1024) void window_rows_kernel(const dg_task_batch b
   }
 }
 
+constexpr int kDenseWaves = DG_DENSE_TILES_PER_BLOCK;
+
+// Dense graphs (dg_csr::dense_bits): Y = A . X on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 with the
+// adjacency bitmap expanded to 0.0 / 1.0 in registers.  A workgroup owns kDenseWaves consecutive 32-row tiles of A
+// (one per wavefront) and one range of its columns (= table rows); the table rows of the range pass through LDS 64
+// at a time (two buffers: the next 64 are on their way while the current ones are multiplied), so every wavefront
+// of the workgroup reads them from there.  Lane (i = lane & 31, kk = lane >> 5) holds the 64-bit word of row i of
+// its tile for the current 64 columns and, per step s, supplies bit 2s + kk as the A operand and
+// table[64 c + 2s + kk][i], [32 + i] as the B operands of the two 32-column halves.  The instruction is a k-ordered
+// fmaf chain and 1.0 * x is exact, so the result is the plain fp32 sum of the neighbour rows in ascending id order
+// -- the order the reference's update_all adds them in.  Table rows come through a buffer descriptor (ids past n
+// read zeros).  The tile's 32 x 64 partial sums go to slab rows row * dense_splits + range; hub_reduce_kernel adds a
+// row's ranges in order and applies the epilogue.
+__global__ __launch_bounds__(64 * kDenseWaves) void dense_rows_kernel(const dg_task_batch batch) {
+  __shared__ f32x4 xs[2][64][16];
+  int ti = 0;
+  for (int k = 0; k < batch.n_tasks; ++k)
+    if (batch.t[k].dense_splits > 0 && (int)blockIdx.x >= batch.t[k].dense_blk_begin) ti = k;
+  const dg_task_dev &T = batch.t[__builtin_amdgcn_readfirstlane(ti)];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
+  const int lb = blockIdx.x - T.dense_blk_begin;
+  const int S = T.dense_splits, group = lb / S, split = lb - group * S;
+  const int tile = group * kDenseWaves + wave;   // (the bitmap is allocated for whole tile groups: a missing tile reads zeros)
+  const float *tab = (T.flags & DG_IN_PRESCALED) ? T.x : T.dense_x;
+  const __amdgpu_buffer_rsrc_t xr = table_rsrc(tab, T.n);
+  const int c0 = split * T.dense_cps, c1 = min(c0 + T.dense_cps, T.dense_chunks);
+  const uint64_t *bits = T.dense_bits + ((size_t)tile * T.dense_chunks) * 32 + i;
+  constexpr int kPer = 1024 / (64 * kDenseWaves);   // float4 per thread of one 64-row stage
+  f32x4 pre[kPer];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const unsigned idx = threadIdx.x + 64 * kDenseWaves * j;   // row idx >> 4 of the stage, float4 idx & 15
+      pre[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(64 * c) * (unsigned)(DG_D * 4) + idx * 16u, 0, 0));
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) (&xs[buf][0][0])[threadIdx.x + 64 * kDenseWaves * j] = pre[j];
+  };
+  f32x16 acc0 = {0.f}, acc1 = {0.f};
+  fetch(c0);
+  uint64_t wn = bits[(size_t)c0 * 32];
+  stash(0);
+  __syncthreads();
+  int cur = 0;
+  for (int c = c0; c < c1; ++c) {
+    const uint64_t wb = wn;
+    if (c + 1 < c1) {
+      fetch(c + 1);
+      wn = bits[(size_t)(c + 1) * 32];
+    }
+    const uint32_t lo = (uint32_t)(wb >> kk), hi = (uint32_t)(wb >> (32 + kk));
+    const float *xb = reinterpret_cast<const float *>(&xs[cur][0][0]) + kk * DG_D + i;
+    // all of the chunk's B operands are asked for before the first product: one exposed LDS round trip per chunk
+    float b0[32], b1[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      b0[s] = xb[2 * s * DG_D];
+      b1[s] = xb[2 * s * DG_D + 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keeps the reads above the products (the scheduler would sink each to its use)
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const float a = (float)(((s < 16 ? lo : hi) >> (2 * (s & 15))) & 1u);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], acc1, 0, 0, 0);
+    }
+    if (c + 1 < c1) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (tile >= T.dense_tiles) return;
+  // register r of lane (i, kk) is tile row (r & 3) + 8 (r >> 2) + 4 kk, feature i (acc0) / 32 + i (acc1)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+    if (row < T.n) {
+      float *dst = T.slab + ((size_t)row * S + split) * DG_D + i;
+      dst[0] = acc0[r];
+      dst[32] = acc1[r];
+    }
+  }
+}
+
+// table * norm of the gathered node, for dense graphs whose input is not scaled yet (the first layer)
+__global__ __launch_bounds__(256) void dense_prescale_kernel(const dg_task_batch batch) {
+  const dg_task_dev &T = batch.t[blockIdx.y];
+  if (T.dense_splits <= 0 || (T.flags & DG_IN_PRESCALED)) return;
+  const int l = threadIdx.x & 15;
+  for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < T.n; row += gridDim.x * 16) {
+    const size_t o = (size_t)row * (DG_D / 4) + l;
+    reinterpret_cast<f32x4 *>(T.dense_x)[o] = reinterpret_cast<const f32x4 *>(T.x)[o] * T.dinv_gather[row];
+  }
+}
+
 // Rows with nothing to gather (last layer of the backward pass): epilogue only, 16 lanes per row.
 __global__ __launch_bounds__(256) void rowwise_kernel(const dg_task_batch batch) {
   const dg_task_dev &T = find_task(batch, blockIdx.x, false);
@@ -576,6 +673,8 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   o.dinv_gather = transpose ? g->dinv_dst : g->dinv_src;
   o.wblocks = c.wblocks; o.woff = c.woff; o.witems = c.witems; o.n_windows = c.n_windows; o.n_parts = c.n_parts;
   o.win_blk_begin = 0; o.win_blk_count = 0;
+  o.dense_bits = c.dense_bits; o.dense_x = g->dense_x; o.dense_splits = c.dense_splits; o.dense_chunks = c.dense_chunks;
+  o.dense_cps = c.dense_cps; o.dense_tiles = c.dense_tiles; o.dense_blk_begin = 0;
   o.colidx = c.colidx; o.head = c.head; o.hub_desc = c.hub_desc; o.seg_desc = c.seg_desc; o.gseg_desc = c.gseg_desc;
   o.colscale = c.colscale; o.head_scale = c.head_scale;
   o.dinv_row = transpose ? g->dinv_src : g->dinv_dst;
@@ -691,7 +790,23 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
       }
     }
   }
+  int32_t dense_blocks = 0;
+  bool dense_prescale = false;
+  for (int k = 0; k < n_tasks; ++k) {
+    dg_task_dev &t = batch.t[k];
+    t.dense_blk_begin = dense_blocks;
+    if (t.dense_splits > 0) {
+      for (int j = 0; j < k; ++j)
+        if (graphs[j] == graphs[k]) return dg_fail(DG_ERR_ARG, "layer tasks %d and %d share a dense graph (one slab per graph)", j, k);
+      dense_blocks += ((t.dense_tiles + kDenseWaves - 1) / kDenseWaves) * t.dense_splits;
+      dense_prescale = dense_prescale || !(t.flags & DG_IN_PRESCALED);
+    }
+  }
   for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
+  if (dense_blocks > 0) {
+    if (dense_prescale) hipLaunchKernelGGL(dense_prescale_kernel, dim3(256, n_tasks), dim3(256), 0, stream, batch);
+    hipLaunchKernelGGL(dense_rows_kernel, dim3(dense_blocks), dim3(64 * kDenseWaves), 0, stream, batch);
+  }
   if (lds_blocks > 0 && full_rows) {
     const size_t lds_bytes = (size_t)(lds_rows_max + 1) * DG_D * sizeof(float);
     static bool lds_attr_set = false;  // more than 64 KiB of dynamic LDS has to be opted into once

@@ -90,9 +90,10 @@ class CSRGraph:
         return self._export(2, self._n, np.float32), self._export(3, self._n, np.float32)
 
     def schedule(self) -> dict:
-        c = self._export(5, 5, np.int32)
-        return {"row_order": self._export(4, int(c[0]) + int(c[1]) + int(c[2]), np.int32), "n_hub": int(c[0]), "n_wave": int(c[1]),
-                "n_group": int(c[2]), "n_seg": int(c[3]), "lds_split": int(c[4])}
+        c = self._export(5, 6, np.int32)
+        order = np.zeros(0, np.int32) if c[5] > 0 else self._export(4, int(c[0]) + int(c[1]) + int(c[2]), np.int32)
+        return {"row_order": order, "n_hub": int(c[0]), "n_wave": int(c[1]), "n_group": int(c[2]), "n_seg": int(c[3]),
+                "lds_split": int(c[4]), "dense_splits": int(c[5])}
 
     def close(self) -> None:
         if self._h is not None:

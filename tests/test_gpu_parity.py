@@ -954,3 +954,72 @@ def test_propagation_backward_random_graphs(seed):
     ((torch.cat([tu, ti]) * r1.double()).sum() + (torch.cat([hu, hi]) * r2.double()).sum()).backward()
     assert_rows_close(m_.embedding_table.grad, torch.cat([ue_.grad, ie_.grad]), rtol=2e-5,
                       what=f"seed {seed} d e0 ({nu} x {ni}, {knobs})")
+
+
+@pytest.mark.parametrize("n,density,directed", [(256, 0.5, False), (300, 0.12, True), (1000, 0.3, False), (2051, 0.45, True)])
+def test_dense_graphs_take_the_bitmap_path(n, density, directed):
+    """Graphs with at least 10 % of all node pairs as edges are contracted as a bitmap on the fp32 matrix cores
+    (dense_rows_kernel) instead of gathered edge by edge: single layer forward and transposed, the fused chain of
+    layers with the running sum, and the backward through it, against the oracle; a repeated edge or a sparse graph
+    keeps the gather path."""
+    rng = np.random.default_rng(n)
+    a = rng.random((n, n)) < density
+    a[5, :] = False; a[:, 5] = False             # an isolated node
+    a[7, :] = True                               # a full row
+    if not directed:
+        a = a | a.T
+    dst, src = np.nonzero(a)                     # row = receiving node
+    src, dst = src.astype(np.int32), dst.astype(np.int32)
+    g = dg.CSRGraph(src, dst, n)
+    assert g.schedule()["dense_splits"] > 0 and g.is_symmetric == (not directed)
+    s_, d_ = T(src.astype(np.int64)), T(dst.astype(np.int64))
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(n))
+    assert_rows_close(ops.spmm_norm_act(g, dev(x), 0.5), O.gcn_layer(s_, d_, n, x, slope=0.5), what="dense layer")
+    assert_rows_close(ops.spmm_norm_act(g, dev(x), 1.0, transpose=True), O.gcn_layer(d_, s_, n, x, slope=None), what="dense layer T")
+    from diffgraph_amd._lib import DG_ACC_REBUILD, DG_IN_PRESCALED, DG_OUT_PRESCALE
+    e0 = dev(x * 0.1)
+    acc, e1 = torch.empty_like(e0), torch.empty_like(e0)
+    ops.gcn_layer_batched([ops.LayerTask(g, e0, e1, None, None, DG_OUT_PRESCALE, 0.5)])
+    ops.gcn_layer_batched([ops.LayerTask(g, e1, None, e0, acc, DG_IN_PRESCALED | DG_ACC_REBUILD, 0.5)])
+    h1 = O.gcn_layer(s_, d_, n, x * 0.1, slope=0.5)
+    h2 = O.gcn_layer(s_, d_, n, h1, slope=0.5)
+    want = x * 0.1 + torch.nn.functional.normalize(h1, p=2, dim=1) + torch.nn.functional.normalize(h2, p=2, dim=1)
+    assert_rows_close(acc, want, rtol=2e-5, what="dense two layers")
+    # same bits on a second launch
+    acc2 = torch.empty_like(acc)
+    ops.gcn_layer_batched([ops.LayerTask(g, e1, None, e0, acc2, DG_IN_PRESCALED | DG_ACC_REBUILD, 0.5)])
+    assert torch.equal(acc, acc2)
+    # a repeated edge cannot be a bit: gather path
+    g2 = dg.CSRGraph(np.concatenate([src, src[:1]]), np.concatenate([dst, dst[:1]]), n)
+    assert g2.schedule()["dense_splits"] == 0
+    assert_rows_close(ops.spmm_norm_act(g2, dev(x), 0.5),
+                      O.gcn_layer(torch.cat([s_, s_[:1]]), torch.cat([d_, d_[:1]]), n, x, slope=0.5), what="repeated edge")
+
+
+def test_dense_graphs_backward_matches_oracle_autograd():
+    """The NC propagation (normalised feed, three layers) over one sparse and two dense graphs in one launch per
+    layer: forward and d/d embed against torch autograd on the oracle."""
+    n = 700
+    rng = np.random.default_rng(3)
+    mats = []
+    for dens in (0.01, 0.3, 0.45):
+        a = rng.random((n, n)) < dens
+        a = a | a.T
+        a[9, :] = False; a[:, 9] = False
+        mats.append(sp.csr_matrix(a.astype(np.float32)))
+    adjs = [dg.CSRGraph.from_scipy(m) for m in mats]
+    assert [g.schedule()["dense_splits"] > 0 for g in adjs] == [False, True, True]
+    model = dg.nc.HGDM(20).eval()
+    gen = torch.Generator().manual_seed(8)
+    embed0 = torch.randn(n, 64, generator=gen) * 0.1
+    rs = [torch.randn(n, 64, generator=gen) for _ in range(3)]
+    embed = dev(embed0).requires_grad_(True)
+    sums = model.propagate(adjs, embed)
+    sum((o * dev(r)).sum() for o, r in zip(sums, rs)).backward()
+    e_cpu = embed0.double().requires_grad_(True)
+    edges = [(T(m.tocoo().row.astype(np.int64)), T(m.tocoo().col.astype(np.int64))) for m in mats]
+    s1, s2, tgt = O.nc_forward(edges, e_cpu, torch.eye(64, dtype=torch.float64), torch.zeros(64, dtype=torch.float64), 3)
+    ((tgt * rs[0].double()).sum() + (s1 * rs[1].double()).sum() + (s2 * rs[2].double()).sum()).backward()
+    for o, want in zip(sums, (tgt, s1, s2)):
+        assert_rows_close(o.detach(), want.detach(), what="dense nc forward")
+    assert_rows_close(embed.grad, e_cpu.grad, rtol=2e-5, what="dense nc d embed")
