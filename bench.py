@@ -30,14 +30,35 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
+def source_digest() -> str:
+    """Digest of the kernel sources: a traffic file counts only for the kernels it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "diffgraph_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "diffgraph_amd", "csrc", "*.h"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(workload: str):
-    """HBM-side bytes per layer launch from the committed PMC passes of this same command (counters cannot be
-    read from inside the run being timed); None when no pass exists for the workload."""
+    """(bytes, source) -- HBM-side bytes per layer launch from the newest profiles/rNN_traffic.json, which
+    tools/collect_profiles.sh writes from rocprofv3 --pmc passes of this same command (counters cannot be read from
+    inside the run being timed).  A file measured on other kernel sources than the ones in the tree is refused:
+    (None, why)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    if not files:
+        return None, "no profiles/rNN_traffic.json"
+    name = os.path.relpath(files[-1], ROOT)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return float(json.load(f)[workload]["traffic_bytes_per_layer_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+        with open(files[-1]) as f:
+            doc = json.load(f)
+        if doc.get("source_digest") != source_digest():
+            return None, f"{name} was measured on other kernel sources (digest {doc.get('source_digest')}): rerun tools/collect_profiles.sh"
+        return float(doc[workload]["traffic_bytes_per_layer_launch"]), f"{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per layer launch (FETCH_SIZE doubled on gfx950)"
+    except (OSError, KeyError, ValueError) as exc:
+        return None, f"{name}: {exc!r}"
 
 
 def parse():
@@ -52,24 +73,57 @@ def parse():
 
 
 class LayerTimer:
-    """HIP events around every propagation-layer launch, on the stream the kernels run on."""
+    """HIP events around every propagation-layer launch, on the stream the kernels run on, keyed by (layer, which
+    tables the launch reads and writes)."""
 
     def __init__(self):
-        self.pairs = []
+        self.records = []
         self.enabled = False
 
-    def __call__(self, phase, layer):
+    def __call__(self, phase, layer, tasks=None):
         if not self.enabled:
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         if phase == "begin":
-            self.pairs.append([layer, ev, None])
+            self.records.append([layer, ev, None, layer_bytes(tasks)])
         else:
-            self.pairs[-1][2] = ev
+            self.records[-1][2] = ev
 
-    def mean_ms(self):
-        return float(np.mean([a.elapsed_time(b) for _, a, b in self.pairs])) if self.pairs else float("nan")
+    def by_key(self):
+        """{(layer, writes): {"ms": mean, "n": launches, "bytes": (algorithmic, compulsory)}}"""
+        out = {}
+        for layer, a, b, by in self.records:
+            key = (layer, by[2])
+            d = out.setdefault(key, {"ms": [], "bytes": by[:2]})
+            d["ms"].append(a.elapsed_time(b))
+        return {k: {"ms": float(np.mean(v["ms"])), "n": len(v["ms"]), "bytes": v["bytes"]} for k, v in out.items()}
+
+
+def layer_bytes(tasks):
+    """(algorithmic, compulsory, label) bytes of one fused layer launch over `tasks` (diffgraph_amd.ops.LayerTask).
+    Algorithmic: 4 nnz + 1032 N per graph -- indices, one read of each source row, write E, read-modify-write the
+    running sum -- whatever the launch's flags.  Compulsory: what THIS launch has to move given its flags: indices
+    (+ per-edge norms while the input is not scaled yet), the 64-B row records (+ their norms), 12 B of per-row
+    scalars, every DISTINCT table it reads once (source table, running sum or e0, the row's own input under
+    DG_ACC_REBUILD) and every table it writes."""
+    from diffgraph_amd._lib import DG_IN_PRESCALED
+    algo = comp = 0
+    reads, label = {}, set()
+    for t in tasks:
+        n, nnz = t.graph.num_nodes(), t.graph.num_edges()
+        algo += 4 * nnz + 1032 * n
+        pre = bool(t.flags & DG_IN_PRESCALED)
+        comp += (4 if pre else 8) * nnz + (64 if pre else 128) * n + 12 * n
+        reads[t.x.data_ptr()] = 256 * n
+        if t.acc_out is not None:
+            reads[t.acc_in.data_ptr()] = 256 * n
+            comp += 256 * n
+            label.add("sum")
+        if t.e_out is not None:
+            comp += 256 * n
+            label.add("E")
+    return algo, comp + sum(reads.values()), "+".join(sorted(label))
 
 
 def build_rec(workload: str, device):
@@ -223,8 +277,7 @@ def main():
         res = dgdist.bench_sharded(args, rank, world, device)
         if res is not None:
             if world == 1:
-                res["roofline"]["traffic"] = measured_traffic(args.workload)
-                res["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc passes of this command)"
+                res["roofline"]["traffic"], res["roofline"]["traffic_source"] = measured_traffic(args.workload)
             if world == 1 and not args.no_cpu_baseline:
                 from diffgraph_amd import data as dgdata
                 res["cpu_baseline"] = cpu_baseline(dgdata.rec_workload(args.workload), passes_per_call=1)
@@ -297,25 +350,43 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    # Kernel-level timing for the roofline: the propagation of the same model state, enqueued
-    # back to back with HIP events around each fused layer launch (events cannot be read back
-    # from inside a graph; back-to-back launches keep host launch gaps out of the intervals).
+    # Kernel-level timing for the roofline, in this same process: HIP events around each fused layer launch of (a) the
+    # step just timed, launched eagerly (events cannot be read back from inside a replayed graph; the kernels and
+    # their arguments are the same), and (b) the inference-mode propagation (HGDM.predict's), back to back.
+    timer.enabled = True
+    for _ in range(max(args.steps // 2, 10)):
+        torch.cuda._sleep(10_000_000)   # the GPU spins ~5 ms while the host queues the step: launches then run back to back,
+        step()                          # and an interval holds kernel time, not the host's launch latency
+    torch.cuda.synchronize()
+    train_layers = timer.by_key()
+    timer.records = []
     with torch.no_grad():
-        for _ in range(5):
+        for _ in range(max(args.steps // 2, 10)):
             model.propagate(model.embedding_table)
-        torch.cuda.synchronize()
-        timer.enabled = True
-        for _ in range(max(args.steps, 20)):
-            model.propagate(model.embedding_table)
-        torch.cuda.synchronize()
-        timer.enabled = False
+    torch.cuda.synchronize()
+    timer.enabled = False
+    infer_layers = timer.by_key()
 
     L = model.n_layers
     nnz = [g.num_edges() for g in graphs]
     edges_per_step = 2 * L * sum(nnz)  # L forward + L backward (transposed) propagation launches per graph
-    layer_bytes = sum(4 * e + 1032 * n for e in nnz)  # fused layer: idx + gather + write E + RMW accumulator
-    layer_ms = timer.mean_ms()
-    achieved = layer_bytes / (layer_ms * 1e-3) / 1e9
+
+    def rows(d, mode):
+        out = []
+        for (layer, writes), v in sorted(d.items()):
+            algo, comp = v["bytes"]
+            sec = v["ms"] * 1e-3
+            out.append({"mode": mode, "layer": layer + 1, "writes": writes, "launches": v["n"], "ms_per_launch": v["ms"],
+                        "bytes_algorithmic": algo, "bytes_compulsory": comp, "frac": algo / sec / 1e9 / HBM_PEAK_GBS,
+                        "frac_compulsory": comp / sec / 1e9 / HBM_PEAK_GBS, "spmm_edges_per_s": sum(nnz) / sec})
+        return out
+    per_layer = rows(train_layers, "training step (forward)") + rows(infer_layers, "inference")
+    fwd = [r for r in per_layer if r["mode"].startswith("training")]
+    layer_bytes_algo = fwd[0]["bytes_algorithmic"]
+    layer_ms = float(np.mean([r["ms_per_launch"] for r in fwd]))          # the forward layer launches of the timed step
+    comp_mean = float(np.mean([r["bytes_compulsory"] for r in fwd]))
+    achieved = layer_bytes_algo / (layer_ms * 1e-3) / 1e9
+    traffic, traffic_source = measured_traffic(workload)
     res = {
         "metric": "SpMM edges/sec + achieved HBM GB/s per propagation layer",
         "value": edges_per_step * args.steps / elapsed,
@@ -327,14 +398,17 @@ def main():
         "config": {"workload": f"{workload}: {wl.note}", "n_user": wl.n_user, "n_item": wl.n_item,
                    "graphs": len(graphs), "directed_edges_per_graph": nnz, "layers": L,
                    "step": "one training step: HGDM.cal_loss (propagation, q_sample + denoiser + SNR loss, BPR) "
-                           "+ backward + Adam; eval-mode dropout",
+                           "+ backward + Adam; eval-mode dropout (the reference's mode from its second epoch on); `value` "
+                           "divides the edges of the step's 2 L propagation launches per graph by the WHOLE step's time",
+                   "spmm_only_edges_per_s": sum(nnz) / (layer_ms * 1e-3),
                    "batch": B, "loss": float(out[0].detach()), "launch": "eager" if args.no_graph else "hip-graph replay"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(workload),
-                     "traffic_source": "profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                       "command, bytes per layer launch (FETCH_SIZE doubled on gfx950)",
-                     "kernel": "gcn_layer_kernel + hub_reduce_kernel (one fused propagation layer, all graphs)",
-                     "bytes_per_launch": layer_bytes, "ms_per_launch": layer_ms},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": "gcn_layer_kernel + hub_reduce_kernel (one fused propagation layer, all graphs; mean over the "
+                               "forward layer launches of the training step)",
+                     "bytes_per_launch": layer_bytes_algo, "ms_per_launch": layer_ms,
+                     "bytes_compulsory": comp_mean, "frac_compulsory": comp_mean / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "per_layer": per_layer},
     }
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(wl)

@@ -371,7 +371,7 @@ def bench_epoch(workload: str, steps: int, warmup: int, cpu_baseline: bool):
     # the propagation layer's launch time for the roofline: HIP events round each fused layer launch, back to back
     pairs = []
 
-    def hook(phase, layer):
+    def hook(phase, layer, tasks=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
         pairs.append(e)

@@ -131,10 +131,10 @@ class HGDM(nn.Module):
                 norms[g].append(rn)
             hook = getattr(self, "layer_hook", None)     # timing hook, as in the Rec model
             if hook is not None:
-                hook("begin", l)
+                hook("begin", l, tasks)
             _launch_distinct(tasks, ops.gcn_layer_batched)
             if hook is not None:
-                hook("end", l)
+                hook("end", l, tasks)
         return sums, saved, norms
 
     def forward(self, he_adjs, feature_list, is_training=True):

@@ -210,10 +210,10 @@ class HGDM(nn.Module):
                 saved[g].append(e_out)
             hook = getattr(self, "layer_hook", None)
             if hook is not None:
-                hook("begin", l)
+                hook("begin", l, tasks)
             ops.gcn_layer_batched(tasks)
             if hook is not None:
-                hook("end", l)
+                hook("end", l, tasks)
         return sums[0], ops.sum_tables(sums[1:]), saved
 
     def forward(self):

@@ -26,8 +26,13 @@ def test_training_step_line_on_the_tiny_workload():
         assert k in r, k
     assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 2 and r["unit"] == "edges/s" and r["value"] > 0
     assert r["vs_baseline"] is None and r["dtype"] == "f32" and "workload" in r["config"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "frac_compulsory", "bytes_compulsory",
+              "per_layer"):
         assert k in r["roofline"], k
+    modes = {(p["mode"], p["layer"]) for p in r["roofline"]["per_layer"]}
+    assert {("inference", 1), ("inference", 2), ("training step (forward)", 1), ("training step (forward)", 2)} <= modes
+    for p in r["roofline"]["per_layer"]:      # what a launch has to move never exceeds the algorithmic model of a full layer
+        assert 0 < p["bytes_compulsory"] <= p["bytes_algorithmic"] and p["ms_per_launch"] > 0
     assert r["roofline"]["bound"] == "hbm" and abs(r["roofline"]["frac"] - r["roofline"]["achieved"] / r["roofline"]["peak"]) < 1e-12
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in r["cpu_baseline"], k

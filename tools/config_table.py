@@ -46,7 +46,7 @@ def measure(name):
     model, graphs, n, run, note = dblp_model() if name == "dblp" else rec_model(name)
     events = []
 
-    def hook(phase, layer):
+    def hook(phase, layer, tasks=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
         events.append((layer, e))

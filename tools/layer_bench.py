@@ -15,7 +15,7 @@ for gm, sl in knobs:
     handler = SimpleNamespace(userNum=wl.n_user, itemNum=wl.n_item, target_adj=graphs[0], behavior_mats=graphs[1:])
     model = dg.rec.HGDM(handler, device=dev).eval()
     ev = []
-    def hook(phase, layer):
+    def hook(phase, layer, tasks=None):
         e = torch.cuda.Event(enable_timing=True); e.record(); ev.append((phase, layer, e))
     with torch.no_grad():
         for _ in range(5):

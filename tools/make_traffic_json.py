@@ -36,5 +36,9 @@ for k in range(0, len(args), 3):
         total += fb + wb
     entry["traffic_bytes_per_layer_launch"] = total
     out[wl] = entry
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["source_digest"] = bench.source_digest()      # bench.py refuses the file once the kernel sources change
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(out, indent=1))
