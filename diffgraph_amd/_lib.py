@@ -160,6 +160,18 @@ def check(rc: int, what: str) -> None:
         raise DiffGraphHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 
+def device_guard(device=None):
+    """Context that makes `device` the current GPU (no-op for None)."""
+    import contextlib
+    import torch
+    if device is None:
+        return contextlib.nullcontext()
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise DiffGraphHipError(f"graphs live on a GPU, got device {device}")
+    return torch.cuda.device(device)
+
+
 def stream_ptr(device=None) -> int:
     import torch
     return torch.cuda.current_stream(device).cuda_stream

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <atomic>
 
 #include "../../include/diffgraph_hip.h"
 
@@ -40,6 +41,19 @@ int dg_fail(int code, const char *fmt, ...);
     hipError_t e_ = (expr);                                                                \
     if (e_ != hipSuccess) return dg_fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
+
+// A kernel that takes more than 64 KiB of dynamic LDS has to be opted in once on every device it runs on
+// (`done`: one bit per device id, owned by the call site).
+inline hipError_t dg_lds_opt_in(const void *kernel, int bytes, std::atomic<uint64_t> &done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 // One direction of a graph: CSR over "rows" (the nodes that receive the sum) with the
 // degree-binned schedule the propagation kernel walks.

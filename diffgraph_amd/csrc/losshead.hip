@@ -38,6 +38,11 @@ __device__ __forceinline__ float sum16(float v) {  // over the 16 lanes of a gro
 }
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
+// Index lists come from the caller (a sampler may hand over -1 for a user with nothing left to draw).
+__device__ __forceinline__ bool in_range(int64_t a, int64_t p, int64_t n, int n_user, int n_item) {
+  return (uint64_t)a < (uint64_t)n_user && (uint64_t)p < (uint64_t)n_item && (uint64_t)n < (uint64_t)n_item;
+}
+
 struct head_rows {
   f32x4 A, P, N;
 };
@@ -57,10 +62,18 @@ __device__ __forceinline__ head_rows load_rows(const float *ui, const float *out
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float *ui, const float *out_u, const float *out_i,
                                                        const double *rl_u, const double *rl_i, const int64_t *ancs,
                                                        const int64_t *poss, const int64_t *negs, int n_batch, int n_user,
-                                                       float *entries_f, double *entries_d) {
+                                                       int n_item, float *entries_f, double *entries_d) {
   const int b = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   if (b >= n_batch) return;
   const int64_t a = ancs[b], p = poss[b], n = negs[b];
+  if (!in_range(a, p, n, n_user, n_item)) {  // nothing is gathered through a bad index: the entry, and with it every loss, is NaN
+    if (l == 0) {
+      float *e = entries_f + (size_t)b * 8;
+      for (int k = 0; k < 8; ++k) e[k] = __builtin_nanf("");
+      entries_d[(size_t)b * 2] = entries_d[(size_t)b * 2 + 1] = __builtin_nan("");
+    }
+    return;
+  }
   const head_rows r = load_rows(ui, out_u, out_i, a, p, n, n_user, l);
   const float s = sum16(dot4(r.A, r.P)) - sum16(dot4(r.A, r.N));  // pairPredict
   const float sig = 1.0f / (1.0f + expf(-s));
@@ -113,15 +126,21 @@ __global__ __launch_bounds__(256) void head_bwd_entries_kernel(const float *ui, 
   if (blockIdx.x == 0 && threadIdx.x == 0) heavy[0] = 0;  // the list head_scatter_kernel fills starts empty
   if (b >= n_batch) return;
   const int64_t a = ancs[b], p = poss[b], n = negs[b];
+  f32x4 *G = reinterpret_cast<f32x4 *>(scratch);
+  int *idx32 = reinterpret_cast<int *>(scratch + (size_t)3 * n_batch * DG_D);  // [3][n_batch]: ancs | poss | negs
+  if (!in_range(a, p, n, n_user, n_rows - n_user)) {  // (the forward made the losses NaN) no row is named, nothing is written
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; ++k) G[((size_t)k * n_batch + b) * 16 + l] = zero;
+    if (l < 3) idx32[l * n_batch + b] = -1;
+    return;
+  }
   const head_rows r = load_rows(ui, out_u, out_i, a, p, n, n_user, l);
   const float c_bpr = (float)((g[0] + g[1]) / batch_div);
   const float c_reg = (float)((g[0] + g[2]) * 2.0 * reg_coef / batch_div);
   const float ds = -c_bpr * (1.0f - entries_f[(size_t)b * 8 + 1]);  // d(-log sigmoid(s))/ds = -(1 - sigmoid(s))
-  f32x4 *G = reinterpret_cast<f32x4 *>(scratch);
   G[((size_t)0 * n_batch + b) * 16 + l] = (r.P - r.N) * ds + r.A * c_reg;
   G[((size_t)1 * n_batch + b) * 16 + l] = r.A * ds + r.P * c_reg;
   G[((size_t)2 * n_batch + b) * 16 + l] = r.A * (-ds) + r.N * c_reg;
-  int *idx32 = reinterpret_cast<int *>(scratch + (size_t)3 * n_batch * DG_D);  // [3][n_batch]: ancs | poss | negs
   // lanes 0..2 register the entry with its table row: first entry (max), count, and -- in arrival
   // order, which the scatter kernel undoes by sorting -- the entry index in one of the row's kSlots slots
   if (l < 3) {
@@ -148,7 +167,9 @@ __global__ __launch_bounds__(256) void head_scatter_kernel(int n_batch, int n_us
   const bool user = e_all < n_batch;
   const int e = user ? e_all : e_all - n_batch, m = user ? n_batch : 2 * n_batch;
   const int *idx32 = reinterpret_cast<const int *>(scratch + (size_t)3 * n_batch * DG_D);  // ancs | poss | negs as int32
-  const int row = idx32[e_all], trow = user ? row : n_user + row, c = cnt[trow];
+  const int row = idx32[e_all];
+  if (row < 0) return;  // entry with an index out of range
+  const int trow = user ? row : n_user + row, c = cnt[trow];
   if (c != 1 && m - tag[trow] != e) return;  // not the only entry naming this row, nor the first of several
   if (c > kSlots) {
     if (l == 0) heavy[1 + atomicAdd(heavy, 1)] = e_all;
@@ -251,7 +272,7 @@ extern "C" int dg_rec_head_fwd(const float *ui, const float *out_u, const float 
   if (n_batch <= 0 || n_batch > kMaxBatch) return dg_fail(DG_ERR_SIZE, "dg_rec_head_fwd: n_batch must be in [1,%d] (got %d)", kMaxBatch, n_batch);
   if (n_user <= 0 || n_item <= 0 || batch_div == 0.0) return dg_fail(DG_ERR_ARG, "dg_rec_head_fwd: bad sizes");
   hipLaunchKernelGGL(head_fwd_kernel, dim3((n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ui, out_u, out_i,
-                     row_loss_u, row_loss_i, ancs, poss, negs, n_batch, n_user, entries_f, entries_d);
+                     row_loss_u, row_loss_i, ancs, poss, negs, n_batch, n_user, n_item, entries_f, entries_d);
   hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, entries_f, entries_d, n_batch, batch_div,
                      reg_coef, results);
   DG_HIP(hipGetLastError());
@@ -279,12 +300,8 @@ extern "C" int dg_rec_head_bwd(const float *ui, const float *out_u, const float 
                      ancs, poss, negs, n_batch, n_user, n_rows, batch_div, reg_coef, entries_f, g, scratch, tag, cnt, slots, heavy);
   hipLaunchKernelGGL(head_scatter_kernel, dim3((3 * n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, n_batch, n_user, g,
                      scratch, tag, cnt, slots, heavy, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
-  static bool attr_set = false;  // more than 64 KiB of dynamic LDS has to be opted into once
-  if (!attr_set) {
-    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(head_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               3 * kMaxBatch * (int)sizeof(int)));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> opted{0};
+  DG_HIP(dg_lds_opt_in(reinterpret_cast<const void *>(head_heavy_kernel), 3 * kMaxBatch * (int)sizeof(int), opted));
   hipLaunchKernelGGL(head_heavy_kernel, dim3(kHeavyBlocks), dim3(16 * kHeavyRuns), 3 * (size_t)n_batch * sizeof(int), (hipStream_t)stream,
                      n_batch, n_user, g, scratch, heavy, d_ui, d_out_u, d_out_i, d_row_loss_u, d_row_loss_i);
   DG_HIP(hipGetLastError());

@@ -91,12 +91,9 @@ extern "C" int dg_spgemm_pattern_rows(const int32_t *a_rowptr, const int32_t *a_
     return dg_fail(DG_ERR_SIZE, "dg_spgemm_pattern_rows: %d columns exceed the %d the row bitmap holds", n_cols, kMaxWords * 32);
   if (n_rows == 0) return 0;
   const size_t lds = (size_t)4 * words * sizeof(uint32_t);
-  static size_t lds_opted = 64 * 1024;  // more dynamic LDS than that has to be opted into
-  if (lds > lds_opted) {
-    DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spgemm_bitmap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               4 * kMaxWords * (int)sizeof(uint32_t)));
-    lds_opted = (size_t)4 * kMaxWords * sizeof(uint32_t);
-  }
+  static std::atomic<uint64_t> opted{0};
+  if (lds > 64 * 1024)
+    DG_HIP(dg_lds_opt_in(reinterpret_cast<const void *>(spgemm_bitmap_kernel), 4 * kMaxWords * (int)sizeof(uint32_t), opted));
   hipLaunchKernelGGL(spgemm_bitmap_kernel, dim3((n_rows + 3) / 4), dim3(256), lds, (hipStream_t)stream, a_rowptr, a_col, n_rows,
                      b_rowptr, b_col, words, bitmap, row_nnz);
   DG_HIP(hipGetLastError());

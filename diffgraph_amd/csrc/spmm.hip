@@ -724,8 +724,13 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
   constexpr int32_t kRowsMask = DG_ROWS_PARTIAL_ONLY | DG_ROWS_FULL_ONLY;
   const int32_t rows_sel = batch.t[0].flags & kRowsMask;
   if (rows_sel == kRowsMask) return dg_fail(DG_ERR_ARG, "layer task: DG_ROWS_PARTIAL_ONLY and DG_ROWS_FULL_ONLY exclude each other");
+  int device = 0;
+  DG_HIP(hipGetDevice(&device));
   for (int k = 0; k < n_tasks; ++k) {
     const dg_task_dev &t = batch.t[k];
+    if (graphs[k]->device != device)
+      return dg_fail(DG_ERR_ARG, "layer task %d: its graph was created on device %d, the current device is %d", k,
+                     graphs[k]->device, device);
     if ((t.flags & kRowsMask) != rows_sel)
       return dg_fail(DG_ERR_ARG, "layer tasks 0 and %d differ in DG_ROWS_PARTIAL_ONLY / DG_ROWS_FULL_ONLY", k);
     if (rows_sel && (t.lds_split <= 0 || !t.partial_out || t.partial_from != t.lds_split))
@@ -809,22 +814,15 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
   }
   if (lds_blocks > 0 && full_rows) {
     const size_t lds_bytes = (size_t)(lds_rows_max + 1) * DG_D * sizeof(float);
-    static bool lds_attr_set = false;  // more than 64 KiB of dynamic LDS has to be opted into once
-    if (!lds_attr_set) {
-      DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lds_rows_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (DG_LDS_MAX_ROWS + 1) * DG_D * (int)sizeof(float)));
-      lds_attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_opted{0};
+    DG_HIP(dg_lds_opt_in(reinterpret_cast<const void *>(lds_rows_kernel), (DG_LDS_MAX_ROWS + 1) * DG_D * (int)sizeof(float),
+                         lds_opted));
     hipLaunchKernelGGL(lds_rows_kernel, dim3(lds_blocks), dim3(1024), lds_bytes, stream, batch);
   }
   if (win_blocks > 0 && partial_rows) {
     constexpr size_t win_lds = (DG_WIN_ROWS + 1) * DG_D * sizeof(float) + DG_WIN_ENT_DWORDS * 4 + 16;
-    static bool win_attr_set = false;
-    if (!win_attr_set) {
-      DG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(window_rows_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds));
-      win_attr_set = true;
-    }
+    static std::atomic<uint64_t> win_opted{0};
+    DG_HIP(dg_lds_opt_in(reinterpret_cast<const void *>(window_rows_kernel), (int)win_lds, win_opted));
     hipLaunchKernelGGL(window_rows_kernel, dim3(win_blocks), dim3(1024), win_lds, stream, batch);
   }
   // (under DG_ROWS_*_ONLY no task has gcn_layer_kernel rows, and every hub row is a partial-sum row)

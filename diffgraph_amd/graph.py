@@ -17,8 +17,10 @@ from . import _lib
 
 class CSRGraph:
     def __init__(self, src, dst, num_nodes: int, group_max: int = 0, seg_len: int = 0, out_degrees=None,
-                 in_degrees=None):
-        """out_degrees / in_degrees (int32[num_nodes]) override the degrees counted from the given
+                 in_degrees=None, device=None):
+        """device: the GPU the graph's arrays live on (default: the current one); layers refuse a graph of another
+        device than the one they are launched on.
+        out_degrees / in_degrees (int32[num_nodes]) override the degrees counted from the given
         edges; a rank holding an edge shard passes the whole graph's degrees.  in_degrees[i] < 0 marks
         node i as not owned: the forward propagation skips that row (row-block partitions)."""
         src = np.ascontiguousarray(np.asarray(src), dtype=np.int32)
@@ -34,10 +36,11 @@ class CSRGraph:
             degs.append(d)
         lib = _lib.load()
         h = C.c_void_p()
-        rc = lib.dg_graph_create_ex(int(num_nodes), int(src.size), src.ctypes.data, dst.ctypes.data,
-                                    None if degs[0] is None else degs[0].ctypes.data,
-                                    None if degs[1] is None else degs[1].ctypes.data,
-                                    int(group_max), int(seg_len), C.byref(h))
+        with _lib.device_guard(device):
+            rc = lib.dg_graph_create_ex(int(num_nodes), int(src.size), src.ctypes.data, dst.ctypes.data,
+                                        None if degs[0] is None else degs[0].ctypes.data,
+                                        None if degs[1] is None else degs[1].ctypes.data,
+                                        int(group_max), int(seg_len), C.byref(h))
         _lib.check(rc, "dg_graph_create_ex")
         self._h = h
         self._n = int(num_nodes)

@@ -24,7 +24,9 @@ class PairwiseTrnData:
         self.cols = np.asarray(coomat.col, dtype=np.int32)
         self.n_user, self.n_item = (int(v) for v in coomat.shape)
         dev = torch.device(device)
-        rowptr, col = _csr(self.rows, self.cols, self.n_user, sort_cols=True)
+        # the look-up rows hold every (user, item) once: a pair stored twice must not make a user look saturated
+        key = np.unique(self.rows.astype(np.int64) * self.n_item + self.cols)
+        rowptr, col = _csr(key // self.n_item, key % self.n_item, self.n_user, sort_cols=True)
         T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.trn_rowptr, self.trn_col = T(rowptr), T(col if col.size else np.zeros(1, np.int32))
         self.rows_dev, self.cols_dev = T(self.rows), T(self.cols)
@@ -45,6 +47,10 @@ class PairwiseTrnData:
                                          len(self.rows), self.n_user, self.n_item, int(seed) & (2 ** 64 - 1),
                                          self.negs_dev.data_ptr(), _lib.stream_ptr(dev))
         _lib.check(rc, "dg_neg_sampling")
+        if len(self.rows) and int(self.negs_dev.min()) < 0:
+            u = int(self.rows_dev[self.negs_dev < 0][0])
+            raise ValueError(f"negSampling: user {u} has interacted with all {self.n_item} items, there is no negative to draw "
+                             "(the reference's loop, DataHandler.py:284-288, would not end)")
 
     def __len__(self):
         return len(self.rows)

@@ -255,6 +255,25 @@ def training_losses2(tab: DiffusionTables, wts: DenoiseWeights, target: torch.Te
     return loss[batch], out
 
 
+# a11: HGDM.cal_loss DiffGraph-Rec/Model.py:94-111 (pairPredict: Utils/Utils.py, (anc*pos).sum(-1) - (anc*neg).sum(-1))
+def rec_cal_loss(tab: DiffusionTables, w_usr: DenoiseWeights, w_item: DenoiseWeights, target, behaviours,
+                 user_emb: torch.Tensor, item_emb: torch.Tensor, ancs, poss, negs, ts_u, noise_u, ts_i, noise_i,
+                 batch: float, reg: float, keep_u: Optional[torch.Tensor] = None, keep_i: Optional[torch.Tensor] = None,
+                 n_layers: int = 2):
+    """Returns (loss, bpr, reg, diffusion loss); the draws of both training_losses2 calls (and, in training mode,
+    both dropout keep masks) are arguments.  batch / reg are args.batch / args.reg of the reference."""
+    tu, ti, hu, hi = rec_forward(target, behaviours, user_emb, item_emb, n_layers)
+    lu, du = training_losses2(tab, w_usr, tu, hu, ancs, ts_u, noise_u, keep_u)
+    li, di = training_losses2(tab, w_item, ti, hi, poss, ts_i, noise_i, keep_i)
+    diff = lu.mean() + li.mean()
+    usr, itm = tu + du, ti + di
+    a, p, n = usr[ancs], itm[poss], itm[negs]
+    score = (a * p).sum(-1) - (a * n).sum(-1)
+    bpr = -score.sigmoid().log().sum() / batch
+    regl = ((torch.norm(a) ** 2 + torch.norm(p) ** 2 + torch.norm(n) ** 2) * reg) / batch
+    return bpr + regl + diff, bpr, regl, diff
+
+
 # --------------------------------------------------------------------------------------
 # Dense normalised-adjacency formulation (used for the cpu_baseline leg): Y = lrelu(A_hat X)
 # --------------------------------------------------------------------------------------

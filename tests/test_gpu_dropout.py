@@ -8,7 +8,7 @@ import torch
 
 import diffgraph_amd as dg
 from diffgraph_amd import data as dgdata, ops
-from tests.helpers import REC_TABLE, assert_rows_close, load, tiny_fixture
+from tests.helpers import GRAD_TOL, REC_TABLE, assert_close_to_max, assert_rows_close, load, tiny_fixture
 from tests.test_gpu_parity import DEV, dev, rec_model, T
 
 pytestmark = pytest.mark.gpu
@@ -52,12 +52,12 @@ def test_rec_cal_loss_train_mode_golden():
     np.testing.assert_allclose([float(v.detach()) for v in (loss, bpr, reg, diff)], tr["losses"], rtol=1e-5)
     loss.backward()
     g = m.embedding_table.grad
-    assert_rows_close(g[:nu], tr["grad_user"], rtol=1e-4, what="grad user_emb")
-    assert_rows_close(g[nu:], tr["grad_item"], rtol=1e-4, what="grad item_emb")
+    assert_rows_close(g[:nu], tr["grad_user"], rtol=1e-5, what="grad user_emb")
+    assert_rows_close(g[nu:], tr["grad_item"], rtol=1e-5, what="grad item_emb")
     for pre, dn in (("usr_", m.usr_denoiser), ("item_", m.item_denoiser)):
         for nm, gv in _grads(dn).items():
             want = tr["grad_" + pre + nm]
-            np.testing.assert_allclose(gv.cpu().numpy(), want, rtol=0, atol=1e-4 * np.abs(want).max(), err_msg="grad " + pre + nm)
+            assert_close_to_max(gv, want, GRAD_TOL, "grad " + pre + nm)
 
 
 def test_nc_cal_loss_train_mode_golden():
@@ -89,7 +89,7 @@ def test_nc_cal_loss_train_mode_golden():
             continue
         want = tr[key]
         assert prm.grad is not None, nm
-        np.testing.assert_allclose(prm.grad.cpu().numpy(), want, rtol=0, atol=1e-4 * np.abs(want).max(), err_msg="grad " + nm)
+        assert_close_to_max(prm.grad, want, GRAD_TOL, "grad " + nm)
         checked += 1
     assert checked == 10
 

@@ -128,26 +128,32 @@ def test_neg_sampling_properties_and_distribution():
     nu, ni = 40, 64
     u, i = dgdata.synth_interactions(nu, ni, 900, 3)
     keep = u >= 2
-    # user 0 has interacted with all items but three; user 1 with every item
-    u = np.concatenate([u[keep], np.zeros(ni - 3, np.int32), np.ones(ni, np.int32)])
-    i = np.concatenate([i[keep], np.arange(3, ni, dtype=np.int32), np.arange(ni, dtype=np.int32)])
+    # user 1 has interacted with every item: there is nothing to draw, and the reference's loop would not end
+    full = PairwiseTrnData(coo(np.concatenate([u[keep], np.ones(ni, np.int32)]),
+                               np.concatenate([i[keep], np.arange(ni, dtype=np.int32)]), nu, ni), seed=7)
+    with pytest.raises(ValueError, match="user 1 has interacted with all"):
+        full.negSampling()
+    # user 0 has interacted with all items but three, and five of those pairs are stored twice (more stored pairs
+    # than there are items: only distinct items count)
+    u = np.concatenate([u[keep], np.zeros(ni - 3, np.int32), np.zeros(5, np.int32)])
+    i = np.concatenate([i[keep], np.arange(3, ni, dtype=np.int32), np.arange(3, 8, dtype=np.int32)])
     train = set(zip(u.tolist(), i.tolist()))
     ds = PairwiseTrnData(coo(u, i, nu, ni), seed=7)
+    assert len(ds) == len(u)
     reps = 300
     draws = []
     for _ in range(reps):                                        # one launch per "epoch", a new stream each
         ds.negSampling()
         draws.append(ds.negs)
     negs, uu = np.concatenate(draws), np.tile(u, reps)
-    ok = uu != 1
-    assert (negs[~ok] == -1).all()
-    assert ((negs[ok] >= 0) & (negs[ok] < ni)).all()
+    ok = np.ones(len(uu), bool)
+    assert ((negs >= 0) & (negs < ni)).all()
     assert not any((int(a), int(b)) in train for a, b in zip(uu[ok][:20000], negs[ok][:20000]))
     assert set(negs[uu == 0].tolist()) == {0, 1, 2}
     ds2 = PairwiseTrnData(coo(u, i, nu, ni), seed=7)
     ds2.negSampling()
     np.testing.assert_array_equal(ds2.negs, draws[0])             # same seed, same epoch: same draws
-    assert (draws[1][u != 1] != draws[0][u != 1]).mean() > 0.5    # the next epoch draws afresh
+    assert (draws[1][u != 0] != draws[0][u != 0]).mean() > 0.5    # the next epoch draws afresh
     # distribution: chi-square of each user's negatives against uniform over its free items, and the same
     # statistic for the oracle's sampler on the same pairs
     sub = np.isin(uu, [2, 3, 4, 5])

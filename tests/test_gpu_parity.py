@@ -8,7 +8,8 @@ import torch
 import diffgraph_amd as dg
 from diffgraph_amd import data as dgdata, ops
 from oracle import ref_cpu as O
-from tests.helpers import (NC_TABLE, REC_TABLE, assert_rows_close, edges_t, load, tiny_fixture, weights_from)
+from tests.helpers import (GRAD_TOL, NC_TABLE, REC_TABLE, assert_close_to_max, assert_rows_close, edges_t, load, tiny_fixture,
+                           weights_from)
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
@@ -363,13 +364,32 @@ def test_rec_loss_head_matches_torch_autograd(n_batch, nu, ni):
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5 if n_batch <= 2048 else 3e-5)
     (got * dev(wts)).sum().backward()
     for nm, g, w in zip(("ui", "out_u", "out_i", "row_loss_u", "row_loss_i"), dl, leaves):
-        scale = float(w.grad.abs().max())
-        np.testing.assert_allclose(g.grad.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * scale, err_msg="grad " + nm)
+        assert_close_to_max(g.grad, w.grad, 2e-5, "head grad " + nm)
     # the same bits on every run (fixed summation order over repeated rows)
     dl2 = [dev(t).requires_grad_(True) for t in (ui, out_u, out_i, rl_u, rl_i)]
     (_RecHeadFn.apply(*dl2, dev(ancs), dev(poss), dev(negs), nu, batch_div, reg) * dev(wts)).sum().backward()
     for g, g2 in zip(dl, dl2):
         assert torch.equal(g.grad, g2.grad)
+
+
+def test_rec_loss_head_index_out_of_range_gives_nan_not_a_gather():
+    """An index outside its table (a sampler's -1, an item id >= n_item) is not gathered through: the four loss
+    values come back NaN, and the backward writes nothing through it (rows no valid entry names keep gradient 0)."""
+    from diffgraph_amd.model_rec import _RecHeadFn
+    gen = torch.Generator().manual_seed(0)
+    nu, ni, nb = 30, 20, 64
+    mk = lambda *s: torch.randn(*s, generator=gen)
+    for which, bad in ((2, -1), (1, ni), (0, nu + 5)):
+        idx = [torch.randint(0, k, (nb,), generator=gen) for k in (nu - 1, ni - 1, ni - 1)]   # last rows never named
+        idx[which][7] = bad
+        dl = [dev(t).requires_grad_(True) for t in (mk(nu + ni, 64), mk(nu, 64), mk(ni, 64), torch.rand(nu, generator=gen).double(),
+                                                     torch.rand(ni, generator=gen).double())]
+        got = _RecHeadFn.apply(*dl, *(dev(t) for t in idx), nu, 64.0, 3e-2)
+        assert torch.isnan(got).all()
+        got.sum().backward()
+        torch.cuda.synchronize()
+        assert (dl[0].grad[nu - 1] == 0).all() and (dl[0].grad[nu + ni - 1] == 0).all()
+        assert (dl[1].grad[nu - 1] == 0).all() and (dl[2].grad[ni - 1] == 0).all()
 
 
 def test_adam_matches_torch_adam_over_steps():
@@ -465,7 +485,7 @@ def test_nc_dblp_golden(tag):
     assert_rows_close(tgt[rows], fx[f"{tag}_target_rows"], rtol=2e-5, what=f"{tag} forward target")
     emb, scores = model.get_allembeds(adjs, dev(features))
     assert_rows_close(emb[rows], fx[f"{tag}_allembeds_rows"], rtol=2e-5, what=f"{tag} allembeds")
-    assert_rows_close(scores[rows], fx[f"{tag}_scores_rows"], rtol=5e-5, what=f"{tag} scores")
+    assert_rows_close(scores[rows], fx[f"{tag}_scores_rows"], rtol=1e-5, what=f"{tag} scores")
     if tag == "coded":
         onehot = torch.zeros(NA, 4)
         onehot[torch.arange(NA), T(load("dblp_graph.npz")["labels"])] = 1.0
@@ -536,15 +556,14 @@ def test_rec_cal_loss_gradients_golden():
     np.testing.assert_allclose([float(v.detach()) for v in (loss, bpr, reg, diff)], fx["cl_losses"], rtol=1e-5)
     loss.backward()
     g = m.embedding_table.grad
-    assert_rows_close(g[:nu], fx["cl_grad_user"], rtol=1e-4, what="grad user_emb")
-    assert_rows_close(g[nu:], fx["cl_grad_item"], rtol=1e-4, what="grad item_emb")
+    assert_rows_close(g[:nu], fx["cl_grad_user"], rtol=1e-5, what="grad user_emb")
+    assert_rows_close(g[nu:], fx["cl_grad_item"], rtol=1e-5, what="grad item_emb")
     for pre, dn in (("usr_", m.usr_denoiser), ("item_", m.item_denoiser)):
         got = {"w_emb": dn.emb_layer.weight.grad, "b_emb": dn.emb_layer.bias.grad, "w_in": dn.in_layers[0].weight.grad,
                "b_in": dn.in_layers[0].bias.grad, "w_out": dn.out_layers[0].weight.grad, "b_out": dn.out_layers[0].bias.grad}
         for nm, gv in got.items():
             want = fx["cl_grad_" + pre + nm]
-            scale = np.abs(want).max()
-            np.testing.assert_allclose(gv.cpu().numpy(), want, rtol=0, atol=1e-4 * scale, err_msg="grad " + pre + nm)
+            assert_close_to_max(gv, want, GRAD_TOL, "grad " + pre + nm)
 
 
 def test_nc_propagation_backward_matches_oracle_autograd():
@@ -610,8 +629,7 @@ def test_nc_cal_loss_gradients_golden():
     for nm, prm in got.items():
         want = fx["tr_grad_" + nm]
         assert prm.grad is not None, nm
-        scale = np.abs(want).max()
-        np.testing.assert_allclose(prm.grad.cpu().numpy(), want, rtol=0, atol=1e-4 * scale, err_msg="grad " + nm)
+        assert_close_to_max(prm.grad, want, GRAD_TOL, "grad " + nm)
 
 
 # ------------------------------------------------------------------------------ (e) sharded
@@ -791,6 +809,18 @@ def test_sharded_lds_graphs_split_layer_calls():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+def test_graph_device_argument():
+    fx, nu, ni, *_ = tiny_fixture()
+    u, i = fx["target_u"], fx["target_i"]
+    g = dg.CSRGraph.from_bipartite(u, i, nu, ni, device="cuda:0")
+    x = dev(torch.randn(nu + ni, 64))
+    out = torch.empty_like(x)
+    ops.gcn_layer_batched([ops.LayerTask(graph=g, x=x, e_out=out, acc_in=None, acc_out=None, flags=0, slope=0.5)])
+    assert torch.isfinite(out).all()
+    with pytest.raises(dg.DiffGraphHipError):
+        dg.CSRGraph.from_bipartite(u, i, nu, ni, device="cpu")
+
+
 def test_row_selection_flags_rejected_for_general_schedules():
     from diffgraph_amd._lib import DG_ROWS_PARTIAL_ONLY, DiffGraphHipError
     fx, nu, ni, target, behs = tiny_fixture()
@@ -832,6 +862,51 @@ def test_ijcai_size_predict_against_oracle():
         want = base[rows] + O.p_sample(tab, _oracle_weights(dn), h[rows], 0)
         assert_rows_close(got[rows.to(DEV)], want, rtol=2e-5, what="ijcai predict " + nm)
     assert torch.isfinite(pu).all() and torch.isfinite(pi).all()
+
+
+def test_tmall_size_forward_and_cal_loss_against_oracle():
+    """The configuration the headline number is quoted on, at full size: the target graph and the three behaviour
+    graphs (31 882 users, 31 232 items, 2 x 1.45 M directed edges each), every row of the four forward outputs
+    against the oracle, then one cal_loss + backward at the reference's batch size (4096) against the oracle under
+    torch autograd: the four loss values, d loss / d embedding table (every row) and the twelve denoiser gradients."""
+    wl = dgdata.rec_workload("tmall")
+    nu, ni = wl.n_user, wl.n_item
+    assert len(wl.behaviours) == 3
+    graphs = [graph_of(*ui, nu, ni) for ui in [wl.target] + wl.behaviours]
+    from types import SimpleNamespace
+    torch.manual_seed(5)
+    m = dg.rec.HGDM(SimpleNamespace(userNum=nu, itemNum=ni, target_adj=graphs[0], behavior_mats=graphs[1:])).eval()
+    ue, ie = T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))
+    m.set_embeddings(dev(ue), dev(ie))
+    with torch.no_grad():
+        fwd = m.forward()
+    target, behs = edges_t(*wl.target, nu), [edges_t(*b, nu) for b in wl.behaviours]
+    want = O.rec_forward(target, behs, ue, ie, 2)
+    for got, w, nm in zip(fwd, want, ("tu", "ti", "hu", "hi")):
+        assert_rows_close(got, w, what="tmall forward " + nm)
+    gen = torch.Generator().manual_seed(17)
+    nb = 4096
+    ancs, poss, negs = (torch.randint(0, k, (nb,), generator=gen) for k in (nu, ni, ni))
+    ts_u, ts_i = (torch.randint(0, REC_TABLE["steps"], (k,), generator=gen) for k in (nu, ni))
+    noise_u, noise_i = torch.randn(nu, 64, generator=gen), torch.randn(ni, 64, generator=gen)
+    batch, reg = float(m.args.batch), float(m.args.reg)
+    loss, bpr, regl, diff = m.cal_loss(dev(ancs), dev(poss), dev(negs), dev(ts_u), dev(noise_u), dev(ts_i), dev(noise_i))
+    loss.backward()
+    ue_, ie_ = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
+    wu, wi = _oracle_weights(m.usr_denoiser), _oracle_weights(m.item_denoiser)
+    for w in (wu, wi):
+        for nm in ("w_emb", "b_emb", "w_in", "b_in", "w_out", "b_out"):
+            getattr(w, nm).requires_grad_(True)
+    o = O.rec_cal_loss(O.DiffusionTables(**REC_TABLE), wu, wi, target, behs, ue_, ie_, ancs, poss, negs, ts_u, noise_u,
+                       ts_i, noise_i, batch, reg)
+    np.testing.assert_allclose([float(v.detach()) for v in (loss, bpr, regl, diff)], [float(v.detach()) for v in o], rtol=1e-5)
+    o[0].backward()
+    assert_rows_close(m.embedding_table.grad, torch.cat([ue_.grad, ie_.grad]), rtol=5e-5, what="tmall d e0")
+    for pre, dn, w in (("usr_", m.usr_denoiser, wu), ("item_", m.item_denoiser, wi)):
+        got = {"w_emb": dn.emb_layer.weight.grad, "b_emb": dn.emb_layer.bias.grad, "w_in": dn.in_layers[0].weight.grad,
+               "b_in": dn.in_layers[0].bias.grad, "w_out": dn.out_layers[0].weight.grad, "b_out": dn.out_layers[0].bias.grad}
+        for nm, gv in got.items():
+            assert_close_to_max(gv, getattr(w, nm).grad, GRAD_TOL, "tmall grad " + pre + nm)
 
 
 def test_industry_size_forward_against_oracle():

@@ -130,7 +130,7 @@ def test_replayed_steps_equal_eager_steps_bit_for_bit(mode):
 def test_replayed_cal_loss_reproduces_the_reference_golden():
     """cal_loss + backward recorded as a HIP graph and replayed, with the reference's recorded draws in static device
     buffers: the four losses and all gradients match the reference's own numbers (the bar of the eager tests)."""
-    from tests.helpers import assert_rows_close, tiny_fixture
+    from tests.helpers import GRAD_TOL, assert_close_to_max, assert_rows_close, tiny_fixture
     from tests.test_gpu_parity import dev, rec_model
     fx, nu, ni, *_ = tiny_fixture()
     m = rec_model(dgdata.rec_workload("tiny"), fx)
@@ -166,14 +166,14 @@ def test_replayed_cal_loss_reproduces_the_reference_golden():
         assert all(torch.equal(p.grad, g) for p, g in zip(m.parameters(), grads))
     np.testing.assert_allclose(res.detach().cpu().numpy(), fx["cl_losses"], rtol=1e-5)
     g = m.embedding_table.grad
-    assert_rows_close(g[:nu], fx["cl_grad_user"], rtol=1e-4, what="grad user_emb")
-    assert_rows_close(g[nu:], fx["cl_grad_item"], rtol=1e-4, what="grad item_emb")
+    assert_rows_close(g[:nu], fx["cl_grad_user"], rtol=1e-5, what="grad user_emb")
+    assert_rows_close(g[nu:], fx["cl_grad_item"], rtol=1e-5, what="grad item_emb")
     for pre, dn in (("usr_", m.usr_denoiser), ("item_", m.item_denoiser)):
         got = {"w_emb": dn.emb_layer.weight.grad, "b_emb": dn.emb_layer.bias.grad, "w_in": dn.in_layers[0].weight.grad,
                "b_in": dn.in_layers[0].bias.grad, "w_out": dn.out_layers[0].weight.grad, "b_out": dn.out_layers[0].bias.grad}
         for nm, gv in got.items():
             want = fx["cl_grad_" + pre + nm]
-            np.testing.assert_allclose(gv.cpu().numpy(), want, rtol=0, atol=1e-4 * np.abs(want).max(), err_msg="grad " + pre + nm)
+            assert_close_to_max(gv, want, GRAD_TOL, "grad " + pre + nm)
     eager = step()
     torch.cuda.synchronize()
     assert torch.equal(eager.detach(), res.detach())

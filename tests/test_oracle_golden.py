@@ -115,16 +115,8 @@ def test_cal_loss_and_gradients():
             setattr(w, nm, getattr(w, nm).clone().requires_grad_(True))
     ancs, poss, negs = T(fx["cl_ancs"]), T(fx["cl_poss"]), T(fx["cl_negs"])
     batch, reg = fx["cl_batch_div"]
-    tu, ti, hu, hi = O.rec_forward(target, behs, ue, ie, 2)
-    lu, du = O.training_losses2(tab, wu, tu, hu, ancs, T(fx["cl_ts_u"]), T(fx["cl_noise_u"]))
-    li, di = O.training_losses2(tab, wi, ti, hi, poss, T(fx["cl_ts_i"]), T(fx["cl_noise_i"]))
-    diff = lu.mean() + li.mean()
-    usr, itm = tu + du, ti + di
-    a, p, n = usr[ancs], itm[poss], itm[negs]
-    score = (a * p).sum(-1) - (a * n).sum(-1)
-    bpr = -score.sigmoid().log().sum() / batch
-    regl = ((torch.norm(a) ** 2 + torch.norm(p) ** 2 + torch.norm(n) ** 2) * reg) / batch
-    loss = bpr + regl + diff
+    loss, bpr, regl, diff = O.rec_cal_loss(tab, wu, wi, target, behs, ue, ie, ancs, poss, negs, T(fx["cl_ts_u"]),
+                                           T(fx["cl_noise_u"]), T(fx["cl_ts_i"]), T(fx["cl_noise_i"]), batch, reg)
     np.testing.assert_allclose([loss.item(), bpr.item(), regl.item(), diff.item()], fx["cl_losses"], rtol=1e-6)
     loss.backward()
     assert_rows_close(ue.grad, fx["cl_grad_user"], rtol=1e-4, what="grad user_emb")
@@ -152,16 +144,9 @@ def test_training_mode_dropout_losses_and_gradients():
             setattr(w, nm, getattr(w, nm).clone().requires_grad_(True))
     ancs, poss, negs = T(fx["cl_ancs"]), T(fx["cl_poss"]), T(fx["cl_negs"])
     batch, reg = fx["cl_batch_div"]
-    tu, ti, hu, hi = O.rec_forward(target, behs, ue, ie, 2)
-    lu, du = O.training_losses2(tab, wu, tu, hu, ancs, T(tr["ts_u"]), T(tr["noise_u"]), T(tr["keep_u"]))
-    li, di = O.training_losses2(tab, wi, ti, hi, poss, T(tr["ts_i"]), T(tr["noise_i"]), T(tr["keep_i"]))
-    diff = lu.mean() + li.mean()
-    usr, itm = tu + du, ti + di
-    a, p, n = usr[ancs], itm[poss], itm[negs]
-    score = (a * p).sum(-1) - (a * n).sum(-1)
-    bpr = -score.sigmoid().log().sum() / batch
-    regl = ((torch.norm(a) ** 2 + torch.norm(p) ** 2 + torch.norm(n) ** 2) * reg) / batch
-    loss = bpr + regl + diff
+    loss, bpr, regl, diff = O.rec_cal_loss(tab, wu, wi, target, behs, ue, ie, ancs, poss, negs, T(tr["ts_u"]),
+                                           T(tr["noise_u"]), T(tr["ts_i"]), T(tr["noise_i"]), batch, reg,
+                                           T(tr["keep_u"]), T(tr["keep_i"]))
     np.testing.assert_allclose([loss.item(), bpr.item(), regl.item(), diff.item()], tr["losses"], rtol=1e-6)
     loss.backward()
     assert_rows_close(ue.grad, tr["grad_user"], rtol=1e-4, what="grad user_emb")
