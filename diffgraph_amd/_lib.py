@@ -59,7 +59,8 @@ class LossTask(C.Structure):
                 ("noise", C.c_void_p), ("ts", C.c_void_p), ("n", C.c_int64), ("out", C.c_void_p), ("row_loss", C.c_void_p),
                 ("g_row_loss", C.c_void_p), ("g_out", C.c_void_p), ("d_target_add", C.c_void_p), ("d_x_start", C.c_void_p),
                 ("d_target", C.c_void_p), ("dout_tot", C.c_void_p), ("hid", C.c_void_p), ("dpre", C.c_void_p),
-                ("xn", C.c_void_p), ("keep_mask", C.c_void_p), ("drop_seed", C.c_void_p), ("drop_p", C.c_float)]
+                ("xn", C.c_void_p), ("keep_mask", C.c_void_p), ("drop_seed", C.c_void_p), ("drop_p", C.c_float),
+                ("wg_tab", C.c_void_p), ("wg_partials", C.c_void_p)]
 
 
 class WgradTask(C.Structure):
@@ -67,6 +68,12 @@ class WgradTask(C.Structure):
                 ("dpre", C.c_void_p), ("xn", C.c_void_p), ("n", C.c_int64), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t), ("d_w_emb", C.c_void_p), ("d_b_emb", C.c_void_p), ("d_w_in", C.c_void_p),
                 ("d_b_in", C.c_void_p), ("d_w_out", C.c_void_p), ("d_b_out", C.c_void_p)]
+
+
+class WgradReduceTask(C.Structure):
+    _fields_ = [("dn", C.POINTER(Denoiser)), ("partials", C.c_void_p), ("n_partials", C.c_int32), ("mk", C.c_void_p),
+                ("d_w_emb", C.c_void_p), ("d_b_emb", C.c_void_p), ("d_w_in", C.c_void_p), ("d_b_in", C.c_void_p),
+                ("d_w_out", C.c_void_p), ("d_b_out", C.c_void_p)]
 
 
 # name -> (restype, argtypes); one entry per symbol declared in include/diffgraph_hip.h
@@ -109,10 +116,14 @@ SIGNATURES = {
                                                 C.c_int32, C.c_void_p]),
     "dg_diffusion_loss_bwd_batched": (C.c_int, [C.POINTER(LossTask), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int32, C.c_void_p]),
+    "dg_diffusion_draw": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dg_dropout_keep_mask": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "dg_denoiser_wgrad_workspace": (C.c_size_t, [C.c_int32]),
     "dg_denoiser_wgrad": (C.c_int, [C.POINTER(Denoiser), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_size_t] + [C.c_void_p] * 7),
+    "dg_wgrad_partial_floats": (C.c_int64, []),
+    "dg_denoiser_wgrad_tab": (C.c_int, [C.POINTER(C.POINTER(Denoiser)), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
+    "dg_denoiser_wgrad_reduce": (C.c_int, [C.POINTER(WgradReduceTask), C.c_int32, C.c_void_p]),
     "dg_denoiser_wgrad_static_max_steps": (C.c_int32, []),
     "dg_denoiser_wgrad_static": (C.c_int, [C.POINTER(Denoiser), C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_int32] +
                                  [C.c_void_p] * 7),

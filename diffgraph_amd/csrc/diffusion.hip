@@ -17,6 +17,7 @@
 // beyond 256 B of bias per step.
 #include "dg_internal.h"
 #include "dg_philox.h"
+#include "dg_wgrad.h"
 
 #include <math.h>
 
@@ -50,7 +51,9 @@ struct dn_task {
   const float *g_out;                 // dL/d out [n][64] or NULL
   float *d_x_start, *d_target;        // [n][64]
   const float *d_target_add;          // [n][64] added into d_target (a gradient that reached the target elsewhere), or NULL
-  float *dout_tot, *hid, *dpre, *xn;  // [n][64] each: operands of the weight-gradient GEMMs
+  float *dout_tot, *hid, *dpre, *xn;  // [n][64] each: operands of the weight-gradient GEMMs (not written when wg_partials is set)
+  const float *wg_tab;                // [n_steps][16] operand table of the time-embedding gradients
+  float *wg_partials;                 // one partial result of the weight gradients per workgroup, or NULL
   // dropout between F.normalize and the first Linear (LOSS and its backward; Model.py:221-224)
   const uint8_t *keep_mask;           // [n][64], nonzero = kept; NULL: drawn from drop_seed
   const int64_t *drop_seed;           // one device word: the key of the draw
@@ -86,6 +89,24 @@ __device__ __forceinline__ void store_tile(float *__restrict__ rowp, int h, bool
     for (int q = 0; q < 4; ++q) {
       f32x4 f = {v[tau][4 * q + 0], v[tau][4 * q + 1], v[tau][4 * q + 2], v[tau][4 * q + 3]};
       *reinterpret_cast<f32x4 *>(rowp + 32 * tau + 8 * q + 4 * h) = f;
+    }
+}
+
+// Weight-gradient staging in LDS: a 32-row tile with rows padded to 68 floats (the 16-byte column pieces of
+// consecutive rows then start in different banks), two tiles per wavefront.
+constexpr int kWgRowFloats = 68, kWgTileFloats = kRowsPerWave * kWgRowFloats;
+constexpr int kWgLdsF4 = kWavesPerBlock * 2 * kWgTileFloats / 4;   // 4352 float4 = 68 KiB (the weight images take 4096)
+static_assert(kWgLdsF4 >= 4 * 2 * 2 * 4 * 64, "the staging area also holds the four weight images");
+
+// Writes the lane's tile (row j, lane half h) row-major into a staged tile; rows outside the table as zeros.
+__device__ __forceinline__ void stage_tile(float *__restrict__ tile, int j, int h, bool valid, const f32x16 (&v)[2]) {
+#pragma unroll
+  for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 f = {v[tau][4 * q + 0], v[tau][4 * q + 1], v[tau][4 * q + 2], v[tau][4 * q + 3]};
+      if (!valid) f = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4 *>(tile + j * kWgRowFloats + 32 * tau + 8 * q + 4 * h) = f;
     }
 }
 
@@ -246,8 +267,9 @@ __global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch bat
 // (q_sample, normalise, two contractions, tanh), then runs the two transposed contractions.
 // The weight gradients are formed by dg_denoiser_wgrad from the dout_tot / hid / dpre / xn tables stored here.
 __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch batch) {
-  // images 0,1: W_in[:, :64], W_out (as in denoise_kernel); 2: W_out^T; 3: W_in[:, :64]^T
-  __shared__ f32x4 wl[4 * 2 * 2 * 4 * 64];
+  // images 0,1: W_in[:, :64], W_out (as in denoise_kernel); 2: W_out^T; 3: W_in[:, :64]^T; afterwards the staging
+  // area of the weight-gradient partials (two padded 32-row tiles per wavefront)
+  __shared__ f32x4 wl[kWgLdsF4];
   const int b = blockIdx.x;
   int ti_ = 0;
   for (int k = 1; k < batch.n_tasks; ++k)
@@ -308,7 +330,8 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
     xd[0] *= dm[0];
     xd[1] *= dm[1];
   }
-  store_tile(T.xn + ro, h, valid, xd);
+  const bool fused = T.wg_partials != nullptr;   // the weight gradients' partial sums are formed here, from registers
+  if (!fused) store_tile(T.xn + ro, h, valid, xd);
   f32x16 hid[2], out[2];
   load_tile(T.time_bias + t * DG_D, h, true, hid);
   contract64(wl, lane, xd, hid);
@@ -316,7 +339,7 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
   for (int tau = 0; tau < 2; ++tau)
 #pragma unroll
     for (int r = 0; r < 16; ++r) hid[tau][r] = tanhf(hid[tau][r]);
-  store_tile(T.hid + ro, h, valid, hid);
+  if (!fused) store_tile(T.hid + ro, h, valid, hid);
   load_tile(T.b_out, h, true, out);
   contract64(wl + 1 * 1024, lane, hid, out);
   // d out = g_out + g_row * w_t * 2 (out - target) / 64 ;  d target = -(second term)
@@ -342,7 +365,7 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
       out[1] += tg[1];
     }
   }
-  store_tile(T.dout_tot + ro, h, valid, out);
+  if (!fused) store_tile(T.dout_tot + ro, h, valid, out);
   // dh = W_out^T dout ; dpre = (1 - h^2) dh
   f32x16 dh[2];
   dh[0] = dh[1] = f32x16{0.f};
@@ -351,7 +374,7 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
   for (int tau = 0; tau < 2; ++tau)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dh[tau][r] = (1.0f - hid[tau][r] * hid[tau][r]) * dh[tau][r];
-  store_tile(T.dpre + ro, h, valid, dh);
+  if (!fused) store_tile(T.dpre + ro, h, valid, dh);
   // dxn = W_in[:, :64]^T dpre ; through F.normalize and q_sample
   f32x16 dx[2];
   dx[0] = dx[1] = f32x16{0.f};
@@ -379,6 +402,85 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
   dx[0] = dx[0] * a_t;
   dx[1] = dx[1] * a_t;
   store_tile(T.d_x_start + ro, h, valid, dx);
+  if (!fused) return;   // (the whole workgroup)
+
+  // ---- weight-gradient partial of this workgroup's 128 rows:  dout^T.hid, dpre^T.xd, dpre^T.tab[ts], column sums
+  // The contraction runs over table rows, so the tiles (row on the lane) go through LDS once to come back with
+  // four rows per wavefront load, 16 lanes per row (the operand layout of dg_wg::mma64).  Each wavefront multiplies
+  // its own 32 rows; the four results are added in wavefront order, wavefront w finishing output rows 4r + w.
+  __syncthreads();   // every wavefront is done with the weight images
+  float *stage_a = reinterpret_cast<float *>(wl) + wave * (2 * kWgTileFloats), *stage_b = stage_a + kWgTileFloats;
+  f32x4 *red = wl;   // [wave][mb * 4 + nb][lane], the four accumulator sets side by side (64 KiB)
+  float *P = T.wg_partials + (size_t)(b - T.blk_begin) * dg_wg::kPartFloats;
+  const int jj = lane & 15, kk = lane >> 4;
+  f32x4 acc[4][4], acc_t[4], cs_out, cs_in;
+  for (int prod = 0; prod < 2; ++prod) {
+    if (prod == 1) __syncthreads();   // the first product's sums have been read
+    stage_tile(stage_a, j, h, valid, prod == 0 ? out : dh);
+    stage_tile(stage_b, j, h, true, prod == 0 ? hid : xd);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      acc_t[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave / 4; ++q) {
+      const f32x4 av = *reinterpret_cast<const f32x4 *>(stage_a + (4 * q + kk) * kWgRowFloats + 4 * jj);
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(stage_b + (4 * q + kk) * kWgRowFloats + 4 * jj);
+      dg_wg::mma64(av, bv, acc);
+      cs += av;
+      if (prod == 1) {   // the time-embedding columns: operand row tab[ts] of table row 4q + kk
+        const int tr = __shfl(t, 4 * q + kk);
+        const bool vr = __shfl((int)valid, 4 * q + kk) != 0;
+        const float tv = vr ? T.wg_tab[tr * dg_wg::kTabCols + jj] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc_t[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], tv, acc_t[mb], 0, 0, 0);
+      }
+    }
+    for (int c = 0; c < 4; ++c) {   // column sums: add the four k-lanes that share jj (fixed order)
+      float v = cs[c];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      cs[c] = v;
+    }
+    if (prod == 0) cs_out = cs; else cs_in = cs;
+    __syncthreads();   // all staged tiles have been read: the area becomes the exchange buffer
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) red[(wave * 16 + mb * 4 + nb) * 64 + lane] = acc[mb][nb];
+    __syncthreads();
+    f32x4 sum[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      sum[nb] = red[(0 * 16 + wave * 4 + nb) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < kWavesPerBlock; ++w) sum[nb] += red[(w * 16 + wave * 4 + nb) * 64 + lane];
+    }
+    dg_wg::store64_mb(P + (prod == 0 ? dg_wg::kPartWout : dg_wg::kPartWin), lane, wave, sum);
+  }
+  __syncthreads();
+  // the small pieces: [wave][0..3] acc_t, [wave][4] column sums of dout, [wave][5] of dpre
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) red[(wave * 6 + mb) * 64 + lane] = acc_t[mb];
+  red[(wave * 6 + 4) * 64 + lane] = cs_out;
+  red[(wave * 6 + 5) * 64 + lane] = cs_in;
+  __syncthreads();
+  {
+    // wavefront w: (dpre^T . tab) rows 4r + w -- acc_t[mb][r] of lane l is o = 16 (l>>4) + 4 r + mb, c = l & 15
+    f32x4 s = red[(0 * 6 + wave) * 64 + lane];
+    for (int w = 1; w < kWavesPerBlock; ++w) s += red[(w * 6 + wave) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) P[dg_wg::kPartTab + (16 * kk + 4 * r + wave) * dg_wg::kTabCols + jj] = s[r];
+    if (wave < 2 && kk == 0) {   // wavefront 0: db_out, wavefront 1: db_in
+      f32x4 c = red[(0 * 6 + 4 + wave) * 64 + lane];
+      for (int w = 1; w < kWavesPerBlock; ++w) c += red[(w * 6 + 4 + wave) * 64 + lane];
+      *reinterpret_cast<f32x4 *>(P + (wave == 0 ? dg_wg::kPartBout : dg_wg::kPartBin) + 4 * jj) = c;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void q_sample_kernel(const f32x4 *__restrict__ x0, const f32x4 *__restrict__ noise,
@@ -615,10 +717,15 @@ int fill_loss_task(const char *who, const dg_loss_task &t, int32_t n_steps, int3
     if (!t.out || !t.row_loss) return dg_fail(DG_ERR_ARG, "%s: NULL output", who);
     k.out = t.out; k.row_loss = t.row_loss;
   } else {
-    if (!t.g_row_loss || !t.d_x_start || !t.d_target || !t.dout_tot || !t.hid || !t.dpre || !t.xn)
-      return dg_fail(DG_ERR_ARG, "%s: NULL backward argument", who);
+    if (!t.g_row_loss || !t.d_x_start || !t.d_target) return dg_fail(DG_ERR_ARG, "%s: NULL backward argument", who);
+    if (t.wg_partials) {
+      if (!t.wg_tab || ((uintptr_t)t.wg_partials & 15)) return dg_fail(DG_ERR_ARG, "%s: wg_partials needs wg_tab and 16-byte alignment", who);
+    } else if (!t.dout_tot || !t.hid || !t.dpre || !t.xn) {
+      return dg_fail(DG_ERR_ARG, "%s: NULL operand table (dout_tot / hid / dpre / xn) and no wg_partials", who);
+    }
     k.g_row = t.g_row_loss; k.g_out = t.g_out; k.d_target_add = t.d_target_add; k.d_x_start = t.d_x_start;
     k.d_target = t.d_target; k.dout_tot = t.dout_tot; k.hid = t.hid; k.dpre = t.dpre; k.xn = t.xn;
+    k.wg_tab = t.wg_tab; k.wg_partials = t.wg_partials;
   }
   return 0;
 }
@@ -681,6 +788,63 @@ __global__ __launch_bounds__(256) void keep_mask_kernel(const int64_t *__restric
   }
 }
 }  // namespace
+
+// -- the random inputs of one training_losses2 call: per-row timesteps and Gaussian noise ----------------
+// (t.randint(0, steps, (batch,)) and t.randn_like(x_start), DiffGraph-Rec/Model.py:352-353.)  The draws come from
+// Philox-4x32-10 keyed by state[0] (the seed); the counter holds the row, the float4 column and state[1], the
+// number of draws made so far, which draw_advance_kernel increments afterwards -- all on the device, so a recorded
+// step draws fresh inputs on every replay, and the same state always gives the same inputs.
+namespace {
+constexpr uint32_t kDrawNoise = 0x100u, kDrawTs = 0x200u, kDrawDropSeed = 0x300u;
+
+__global__ __launch_bounds__(256) void draw_kernel(const int64_t *__restrict__ state, int64_t n, int32_t n_steps,
+                                                   int64_t *__restrict__ ts, f32x4 *__restrict__ noise) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (row, float4 column)
+  if (i >= n * (DG_D / 4)) return;
+  const uint64_t seed = (uint64_t)state[0], draw = (uint64_t)state[1];
+  const uint64_t row = (uint64_t)(i >> 4);
+  const uint32_t j = (uint32_t)(i & 15), hi = (uint32_t)(draw >> 32) << 16;
+  if (noise != nullptr) {
+    // two Box-Muller pairs from four 24-bit uniforms: u1 in (0,1], u2 in [0,1)
+    const dg_u32x4 r = dg_philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), kDrawNoise | j | hi, (uint32_t)draw, (uint32_t)seed,
+                                        (uint32_t)(seed >> 32));
+    const float k = 1.0f / 16777216.0f;
+    const float ra = sqrtf(-2.0f * logf(((float)(r.x >> 8) + 1.0f) * k)), rb = sqrtf(-2.0f * logf(((float)(r.z >> 8) + 1.0f) * k));
+    float sa, ca, sb, cb;
+    sincospif(2.0f * (float)(r.y >> 8) * k, &sa, &ca);
+    sincospif(2.0f * (float)(r.w >> 8) * k, &sb, &cb);
+    noise[i] = f32x4{ra * ca, ra * sa, rb * cb, rb * sb};
+  }
+  if (j == 0 && ts != nullptr) {
+    const dg_u32x4 r = dg_philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), kDrawTs | hi, (uint32_t)draw, (uint32_t)seed,
+                                        (uint32_t)(seed >> 32));
+    ts[row] = (int64_t)(((uint64_t)r.x * (uint64_t)n_steps) >> 32);
+  }
+}
+
+// state[1] += 1, and state[2] = the key of this draw's dropout masks (what dg_loss_task.drop_seed may point at)
+__global__ void draw_advance_kernel(int64_t *state) {
+  const uint64_t seed = (uint64_t)state[0], draw = (uint64_t)state[1];
+  const dg_u32x4 r = dg_philox4x32_10(0u, 0u, kDrawDropSeed | ((uint32_t)(draw >> 32) << 16), (uint32_t)draw, (uint32_t)seed,
+                                      (uint32_t)(seed >> 32));
+  state[2] = (int64_t)((((uint64_t)r.x << 32) | r.y) >> 2);
+  state[1] = (int64_t)(draw + 1);
+}
+}  // namespace
+
+extern "C" int dg_diffusion_draw(int64_t *state, int64_t n, int32_t n_steps, int32_t d, int64_t *ts, float *noise, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_diffusion_draw: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!state || n < 0 || n_steps <= 0) return dg_fail(DG_ERR_ARG, "dg_diffusion_draw: bad argument");
+  if (((uintptr_t)noise & 15) || ((uintptr_t)state & 7)) return dg_fail(DG_ERR_ARG, "dg_diffusion_draw: misaligned pointer");
+  const int64_t blocks = (n * (DG_D / 4) + 255) / 256;
+  if (blocks > 0x7fffffff) return dg_fail(DG_ERR_SIZE, "dg_diffusion_draw: too many rows");
+  if (blocks > 0 && (ts || noise))
+    hipLaunchKernelGGL(draw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, state, n, n_steps, ts,
+                       reinterpret_cast<f32x4 *>(noise));
+  hipLaunchKernelGGL(draw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int dg_dropout_keep_mask(const int64_t *drop_seed, int32_t task, float drop_p, int64_t n, int32_t d, uint8_t *mask,
                                     void *stream) {

@@ -16,19 +16,25 @@
 // per-workgroup partial results in workgroup order, so the gradients are the same bits on every
 // run (no float atomics) and nothing depends on a BLAS workspace or semaphore.
 #include "dg_internal.h"
+#include "dg_wgrad.h"
 
 #include <math.h>
 #include <mutex>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using dg_wg::f32x4;
+using dg_wg::kPartBin;
+using dg_wg::kPartBout;
+using dg_wg::kPartFloats;
+using dg_wg::kPartTab;
+using dg_wg::kPartWin;
+using dg_wg::kPartWout;
+using dg_wg::kTabCols;
+using dg_wg::mma64;
+using dg_wg::store64;
 
 namespace {
 
 constexpr int kGroups = 256;          // workgroups of the partial launch = partial results to add
-constexpr int kTabCols = 16;          // per-timestep operand row: emb[t] (8) | te[t] (8)
-// floats of one partial result: dW_out, dW_in[:, :64], dpre^T.tab (64x16), db_out, db_in
-constexpr int kPartWout = 0, kPartWin = 4096, kPartTab = 8192, kPartBout = 9216, kPartBin = 9280;
-constexpr int kPartFloats = 9344;
 
 struct wg_args {
   const float *dout, *hid, *dpre, *xn;
@@ -75,28 +81,6 @@ __global__ __launch_bounds__(256) void wgrad_tab_kernel(const per_task<tab_args>
     tab[t * kTabCols + e] = emb + a.b_emb[e];
     tab[t * kTabCols + 8 + e] = te[e];
   }
-}
-
-// acc[mb][nb] += A-tile mb (features 4j+mb of the `a` rows) ^T . B-tile nb (features 4j+nb of the `b` rows)
-__device__ __forceinline__ void mma64(const f32x4 a, const f32x4 b, f32x4 (&acc)[4][4]) {
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-}
-
-// Element (o, i) of a 64x64 product sits in acc[mb][nb][r] of lane l with
-//   o = 16 (l>>4) + 4 r + mb,  i = 4 (l&15) + nb:   the four nb of one (mb, r) are a contiguous float4.
-__device__ __forceinline__ void store64(float *dst, int lane, const f32x4 (&acc)[4][4]) {
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = 16 * (lane >> 4) + 4 * r + mb;
-      *reinterpret_cast<f32x4 *>(dst + o * 64 + 4 * (lane & 15)) =
-          f32x4{acc[mb][0][r], acc[mb][1][r], acc[mb][2][r], acc[mb][3][r]};
-    }
 }
 
 struct wg_operands {
@@ -197,20 +181,22 @@ __global__ __launch_bounds__(512) void wgrad_partial_kernel(const per_task<wg_ar
 
 struct fin_args {
   const float *partials;
+  int32_t n_partials;
   float *d_w_in, *d_b_in, *d_w_out, *d_b_out;
   float *mk;  // [64][8] dpre^T . te[ts], for wgrad_emb_kernel
 };
 
-// A workgroup finishes 32 floats of the result: thread (slice, f) adds 1/8 of the kGroups partials of
-// float f in order, then the eight slice sums are added in slice order -- a fixed order overall.
+// A workgroup finishes 32 floats of the result: thread (slice, f) adds 1/8 of the partials of float f in
+// order, then the eight slice sums are added in slice order -- a fixed order overall.
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const per_task<fin_args> all) {
   const fin_args &a = all.t[blockIdx.y];
   __shared__ float part[8][32];
   const int slice = threadIdx.x >> 5, f = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int per = (a.n_partials + 7) / 8;
   float s = 0.f;
   if (f < kPartFloats)
 #pragma unroll 8
-    for (int g = slice * (kGroups / 8); g < (slice + 1) * (kGroups / 8); ++g) s += a.partials[(size_t)g * kPartFloats + f];
+    for (int g = slice * per; g < min((slice + 1) * per, a.n_partials); ++g) s += a.partials[(size_t)g * kPartFloats + f];
   part[slice][threadIdx.x & 31] = s;
   __syncthreads();
   if (slice != 0 || f >= kPartFloats) return;
@@ -294,7 +280,7 @@ extern "C" int dg_denoiser_wgrad_batched(const dg_wgrad_task *tasks, int32_t n_t
     w.rows_per_group = ((t.n + kGroups - 1) / kGroups + 15) / 16 * 16;
     if (w.rows_per_group == 0) w.rows_per_group = 16;
     fin_args &f = fa.t[k];
-    f.partials = partials; f.d_w_in = t.d_w_in; f.d_b_in = t.d_b_in; f.d_w_out = t.d_w_out; f.d_b_out = t.d_b_out; f.mk = mk;
+    f.partials = partials; f.n_partials = kGroups; f.d_w_in = t.d_w_in; f.d_b_in = t.d_b_in; f.d_w_out = t.d_w_out; f.d_b_out = t.d_b_out; f.mk = mk;
     emb_args &e = ea.t[k];
     e.w_in = dn->w_in; e.mk = mk; e.d_b_in = t.d_b_in; e.d_w_emb = t.d_w_emb; e.d_b_emb = t.d_b_emb;
   }
@@ -317,6 +303,53 @@ extern "C" int dg_denoiser_wgrad(const dg_denoiser *dn, int32_t n_steps, const i
   t.workspace = workspace; t.workspace_bytes = workspace_bytes;
   t.d_w_emb = d_w_emb; t.d_b_emb = d_b_emb; t.d_w_in = d_w_in; t.d_b_in = d_b_in; t.d_w_out = d_w_out; t.d_b_out = d_b_out;
   return dg_denoiser_wgrad_batched(&t, 1, n_steps, d, stream);
+}
+
+// -- the weight gradients from partial results the loss backward kernel formed itself -------------------
+// (dg_loss_task.wg_partials: one partial per 128 table rows, nothing of the four [n][64] operand tables is written)
+extern "C" int64_t dg_wgrad_partial_floats(void) { return kPartFloats; }
+
+extern "C" int dg_denoiser_wgrad_tab(const dg_denoiser *const *dns, float *const *tabs, int32_t n_tabs, int32_t n_steps,
+                                     void *stream) {
+  if (!dns || !tabs || n_tabs <= 0 || n_tabs > kMaxTasks)
+    return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad_tab: n_tabs must be in [1,%d] (got %d)", kMaxTasks, n_tabs);
+  if (n_steps <= 0) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad_tab: n_steps must be positive");
+  per_task<tab_args> ta;
+  for (int k = 0; k < n_tabs; ++k) {
+    const dg_denoiser *dn = dns[k];
+    if (!dn || !dn->w_emb || !dn->b_emb || !dn->freqs_host || !tabs[k]) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad_tab: NULL argument");
+    tab_args &a = ta.t[k];
+    a.w_emb = dn->w_emb; a.b_emb = dn->b_emb; a.n_steps = n_steps; a.tab = tabs[k];
+    for (int f = 0; f < 4; ++f) a.freqs[f] = dn->freqs_host[f];
+  }
+  for (int k = n_tabs; k < kMaxTasks; ++k) ta.t[k] = ta.t[0];
+  hipLaunchKernelGGL(wgrad_tab_kernel, dim3((n_steps + 255) / 256, n_tabs), dim3(256), 0, (hipStream_t)stream, ta);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dg_denoiser_wgrad_reduce(const dg_wgrad_reduce_task *tasks, int32_t n_tasks, void *stream) {
+  if (!tasks || n_tasks <= 0 || n_tasks > kMaxTasks)
+    return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad_reduce: n_tasks must be in [1,%d] (got %d)", kMaxTasks, n_tasks);
+  per_task<fin_args> fa;
+  per_task<emb_args> ea;
+  for (int k = 0; k < n_tasks; ++k) {
+    const dg_wgrad_reduce_task &t = tasks[k];
+    if (!t.dn || !t.dn->w_in || !t.partials || !t.mk || !t.d_w_emb || !t.d_b_emb || !t.d_w_in || !t.d_b_in || !t.d_w_out || !t.d_b_out)
+      return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad_reduce: NULL argument (task %d)", k);
+    if (t.n_partials < 0) return dg_fail(DG_ERR_ARG, "dg_denoiser_wgrad_reduce: negative partial count (task %d)", k);
+    fin_args &f = fa.t[k];
+    f.partials = t.partials; f.n_partials = t.n_partials; f.d_w_in = t.d_w_in; f.d_b_in = t.d_b_in; f.d_w_out = t.d_w_out;
+    f.d_b_out = t.d_b_out; f.mk = t.mk;
+    emb_args &e = ea.t[k];
+    e.w_in = t.dn->w_in; e.mk = t.mk; e.d_b_in = t.d_b_in; e.d_w_emb = t.d_w_emb; e.d_b_emb = t.d_b_emb;
+  }
+  for (int k = n_tasks; k < kMaxTasks; ++k) { fa.t[k] = fa.t[0]; ea.t[k] = ea.t[0]; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((kPartFloats + 31) / 32, n_tasks), dim3(256), 0, s, fa);
+  hipLaunchKernelGGL(wgrad_emb_kernel, dim3(1, n_tasks), dim3(128), 0, s, ea);
+  DG_HIP(hipGetLastError());
+  return 0;
 }
 
 // -- the same without a workspace argument, for callers that cannot allocate --------------------------

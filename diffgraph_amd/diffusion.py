@@ -73,19 +73,27 @@ class Denoise(nn.Module):
         return ops.denoise_fwd(p, x.contiguous(), timesteps, n_steps)
 
 
-def dropout_args(models, keep_mask, device):
-    """(drop_p, keep_mask, drop_seed) for a loss call through `models` (Denoise modules): dropout is on when they are
-    in training mode with p > 0 (Model.py:223-224).  Without a caller-supplied mask a fresh key for the in-kernel
-    draw is taken from torch's generator (one int64 on the device, so a captured step draws a new mask per replay)."""
+def dropout_rate(models) -> float:
+    """The dropout probability of a loss call through `models` (Denoise modules): p while they are in training mode
+    (Model.py:223-224), else 0."""
     ps = {float(m.drop.p) if m.training else 0.0 for m in models}
     if len(ps) != 1:
         raise DiffGraphHipError("the denoisers of one loss call must share their training mode and dropout rate")
-    p = ps.pop()
+    return max(ps.pop(), 0.0)
+
+
+def dropout_args(models, keep_mask, device, drop_seed=None):
+    """(drop_p, keep_mask, drop_seed) for a loss call through `models`.  Without a caller-supplied mask the kernels
+    draw one from the key `drop_seed` (int64[1] on the device; default: a fresh one from torch's generator -- a device
+    word, so a captured step draws a new mask per replay)."""
+    p = dropout_rate(models)
     if p <= 0.0:
         return 0.0, None, None
     if keep_mask is not None:
         return p, keep_mask.contiguous().view(torch.uint8) if keep_mask.dtype == torch.bool else keep_mask.contiguous(), None
-    return p, None, torch.randint(0, 2 ** 62, (1,), device=device, dtype=torch.int64)
+    if drop_seed is None:
+        drop_seed = torch.randint(0, 2 ** 62, (1,), device=device, dtype=torch.int64)
+    return p, None, drop_seed
 
 
 class _DiffusionLossFn(torch.autograd.Function):

@@ -13,6 +13,7 @@ next one, and adds the L2-normalised activation into that graph's running sum.
 """
 from __future__ import annotations
 
+from contextlib import contextmanager
 from types import SimpleNamespace
 from typing import List, Optional
 
@@ -21,7 +22,7 @@ from torch import nn
 
 from . import ops
 from ._lib import DG_ACC_REBUILD, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
-from .diffusion import Denoise, GaussianDiffusion, dropout_args
+from .diffusion import Denoise, GaussianDiffusion, dropout_args, dropout_rate
 from .layers import DGLLayer
 
 DEFAULT_ARGS = SimpleNamespace(latdim=64, gcn_layer=2, dims="[64]", d_emb_size=8, norm=True, steps=200,
@@ -114,8 +115,7 @@ class _RecLossFn(torch.autograd.Function):
         drop_p, keep_mask, drop_seed = drop
         spans = []
         for dn, begin, n in ((model.usr_denoiser, 0, nu), (model.item_denoiser, nu, model.n_item)):
-            spans.append(ops.LossSpan(dn.params(bool(dn.norm)), begin, n, drop_p))
-        ops.refresh_time_bias([sp.dn for sp in spans], gd.steps)      # both denoisers' tables, one launch
+            spans.append(ops.LossSpan(dn.params(bool(dn.norm)), begin, n, drop_p))   # (time-bias tables: cal_loss_vector)
         sa = gd._dev("sqrt_alphas_cumprod", dev) if gd.noise_scale != 0 else None
         sb = gd._dev("sqrt_one_minus_alphas_cumprod", dev) if gd.noise_scale != 0 else None
         lw = gd._dev("loss_weight", dev, torch.float64)
@@ -134,11 +134,19 @@ class _RecLossFn(torch.autograd.Function):
         gd, args, nu = model.diffusion_process, model.args, model.n_user
         d_ui_head, d_out, d_rl = ops.rec_head_bwd(ui, out[:nu], out[nu:], ancs, poss, negs, nu, float(args.batch),
                                                   float(args.reg), ent_f, g.contiguous(), full=True)
-        d_het, d_ui, dout, hid, dpre, xn = ops.diffusion_loss_bwd_spans(spans, ui, het, noise, ts, sa, sb, lw, d_rl, d_out,
-                                                                        d_target_add=d_ui_head, keep_mask=keep_mask,
-                                                                        drop_seed=drop_seed)
-        jobs = [(sp.dn,) + tuple(t[sp.begin: sp.begin + sp.n] for t in (ts, dout, hid, dpre, xn)) for sp in spans]
-        grads = [g for res in ops.denoiser_wgrad_many(jobs, gd.steps) for g in res]   # both denoisers, one set of launches
+        # one launch for both diffusion losses; it also sums the weight gradients' operands over its 128-row strips
+        d_het, d_ui, partials = ops.diffusion_loss_bwd_spans(spans, ui, het, noise, ts, sa, sb, lw, d_rl, d_out,
+                                                             d_target_add=d_ui_head, keep_mask=keep_mask,
+                                                             drop_seed=drop_seed, fused_wgrad=True)
+        jobs = [(sp.dn, part) for sp, part in zip(spans, partials)]
+        if model.side_join_deferred:
+            # a caller that promises run_late_side_work() before it touches the gradients (training_step): the strips'
+            # sums are added up after the propagation's backward pass is launched and beside it, from here on
+            res, go = ops.denoiser_wgrad_reduce(jobs, launch=False)
+            model._late_side = (model.fork_point(), go)
+        else:
+            res = ops.denoiser_wgrad_reduce(jobs)               # both denoisers, one set of launches
+        grads = [g for r in res for g in r]
         return (d_ui, d_het, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
@@ -167,6 +175,63 @@ class HGDM(nn.Module):
         in_dims = out_dims[::-1]
         self.usr_denoiser = Denoise(in_dims, out_dims, args.d_emb_size, norm=args.norm).to(device)
         self.item_denoiser = Denoise(in_dims, out_dims, args.d_emb_size, norm=args.norm).to(device)
+        # {seed, draws made, dropout key, 0} of the timesteps / noise / dropout masks drawn on the device
+        self.register_buffer("draw_state", ops.new_draw_state(device), persistent=False)
+        self._side: Optional[torch.cuda.Stream] = None
+        self._side_pending: list = []
+        self._late_side = None
+        self.side_join_deferred = False
+
+    # -- work beside the main stream --------------------------------------------------------------------
+    # The propagation kernels wait on memory most of the time; short launches that do not depend on them (the
+    # step's random draws and time-bias tables in the forward pass, the denoisers' weight gradients and their Adam
+    # update in the backward pass) run on a second stream meanwhile.  Recorded into a HIP graph the fork and the
+    # join become branches of the graph.
+    def _side_stream(self) -> torch.cuda.Stream:
+        dev = self.embedding_table.device
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(dev)
+        return self._side
+
+    def fork_point(self) -> torch.cuda.Event:
+        """Marks the current position of the current stream: side_work(after=...) starts behind it."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.embedding_table.device))
+        return ev
+
+    @contextmanager
+    def side_work(self, keep=None, after: Optional[torch.cuda.Event] = None):
+        """Runs the block on the side stream, after everything launched so far on the current one (or up to the
+        fork_point `after`).  The current stream does not wait for it until join_side_work(); `keep` holds what the
+        block reads alive until then, so that its memory is not handed out again meanwhile."""
+        dev = self.embedding_table.device
+        main, side = torch.cuda.current_stream(dev), self._side_stream()
+        if after is None:
+            side.wait_stream(main)
+        else:
+            side.wait_event(after)
+        self._side_pending.append(keep)
+        with torch.cuda.stream(side):
+            yield
+
+    def run_late_side_work(self, then=None) -> None:
+        """Launches what a backward pass under side_join_deferred left for later (and `then`, e.g. the update of the
+        parameters whose gradients it forms) on the side stream, and joins."""
+        if self._late_side is not None:
+            after, go = self._late_side
+            self._late_side = None
+            with self.side_work(after=after):
+                go()
+                if then is not None:
+                    then()
+        elif then is not None:
+            then()
+        self.join_side_work()
+
+    def join_side_work(self) -> None:
+        if self._side_pending:
+            torch.cuda.current_stream(self.embedding_table.device).wait_stream(self._side_stream())
+            self._side_pending = []
 
     @property
     def embedding_dict(self):
@@ -231,22 +296,36 @@ class HGDM(nn.Module):
         e = [1, 0, 0, 0] is `loss.backward()` without the kernels autograd spends on slicing the scalar out.
         In training mode the denoisers' dropout (Model.py:223-224) runs inside the loss kernels, over the
         elements keep_u [n_user, 64] / keep_i [n_item, 64] keep (bool or uint8) or over a fresh draw."""
-        ui, het = self.propagate(self.embedding_table)   # [users | items] tables: target-graph sums, behaviour sums
         dp = self.diffusion_process
-        n = ui.shape[0]
+        dev, n = self.embedding_table.device, self.n_user + self.n_item
+        denoisers = [self.usr_denoiser, self.item_denoiser]
         if validate is None:   # caller-supplied timesteps are range-checked (one host sync) unless the caller vouches for them
             validate = ts_u is not None or ts_i is not None
-        if ts_u is None and ts_i is None:
-            ts = torch.randint(0, dp.steps, (n,), device=ui.device).long()           # Model.py:352, both calls at once
-        else:
-            ts = torch.cat([ts_u, ts_i]).long().contiguous()
-        noise = None
-        if dp.noise_scale != 0:
-            noise = torch.randn_like(ui) if noise_u is None and noise_i is None else torch.cat([noise_u, noise_i]).contiguous()
         keep = None
         if keep_u is not None or keep_i is not None:
             keep = torch.cat([keep_u.to(torch.uint8), keep_i.to(torch.uint8)]).contiguous()
-        drop = dropout_args([self.usr_denoiser, self.item_denoiser], keep, ui.device)
+        # what the call has to draw itself: timesteps and noise of both training_losses2 calls at once
+        # (Model.py:352-353) and the key of the dropout masks
+        need_ts = ts_u is None and ts_i is None
+        need_noise = dp.noise_scale != 0 and noise_u is None and noise_i is None
+        need_key = dropout_rate(denoisers) > 0 and keep is None
+        ts = torch.empty(n, dtype=torch.int64, device=dev) if need_ts else torch.cat([ts_u, ts_i]).long().contiguous()
+        noise = None
+        if dp.noise_scale != 0:
+            noise = torch.empty((n, DG_D), device=dev) if need_noise else torch.cat([noise_u, noise_i]).contiguous()
+        start = self.fork_point()
+        ui, het = self.propagate(self.embedding_table)   # [users | items] tables: target-graph sums, behaviour sums
+        # beside the propagation (launched after it, started before it): the draws and both denoisers' time-bias tables
+        with self.side_work(after=start):
+            if need_ts or need_noise or need_key:
+                ops.diffusion_draw(self.draw_state, n, dp.steps, need_ts, need_noise, ts if need_ts else None,
+                                   noise if need_noise else None)
+            params = [dn.params(bool(dn.norm)) for dn in denoisers]
+            ops.refresh_time_bias(params, dp.steps)
+            if torch.is_grad_enabled():
+                ops.wgrad_operand_tables(params, dp.steps)     # the backward pass's time-embedding operands
+        self.join_side_work()
+        drop = dropout_args(denoisers, keep, dev, self.draw_state[2:3])
         ancs, poss, negs = (v.long().contiguous() for v in (ancs, poss, negs))
         weights = []
         for dn in (self.usr_denoiser, self.item_denoiser):

@@ -238,6 +238,7 @@ class DenoiserParams:
         self.device = self.tensors[0].device
         self._tb = None
         self._tb_steps = 0
+        self.wg_tab = None      # [n_steps, 16] operand table of the fused weight gradients (wgrad_operand_tables)
 
     def time_bias(self, n_steps: int, refresh: bool = False) -> torch.Tensor:
         if self._tb is None or self._tb_steps != n_steps or refresh:
@@ -384,6 +385,29 @@ class LossSpan:
     drop_p: float = 0.0
 
 
+def new_draw_state(device, seed: Optional[int] = None) -> torch.Tensor:
+    """int64[4] on `device`: {seed (default: torch's initial seed), draws made so far, dropout key of the last draw, 0}."""
+    seed = torch.initial_seed() if seed is None else int(seed)
+    return torch.tensor([seed & (2 ** 63 - 1), 0, 0, 0], dtype=torch.int64, device=device)
+
+
+def diffusion_draw(state: torch.Tensor, n: int, n_steps: int, ts: bool = True, noise: bool = True, out_ts=None, out_noise=None):
+    """(ts int64[n], noise fp32[n, 64]) of one training_losses2 call from `state` (new_draw_state), which moves on by
+    one draw; state[2:3] afterwards keys the dropout masks of the same call.  out_ts / out_noise: buffers to fill."""
+    _vec(state, "draw state", torch.int64, 4)
+    dev = state.device
+    t = (torch.empty(n, dtype=torch.int64, device=dev) if out_ts is None else out_ts) if ts else None
+    z = (torch.empty((n, DG_D), dtype=torch.float32, device=dev) if out_noise is None else out_noise) if noise else None
+    if t is not None:
+        _vec(t, "ts", torch.int64, n)
+    if z is not None:
+        _table(z, "noise", n)
+    rc = _lib.load().dg_diffusion_draw(state.data_ptr(), n, int(n_steps), DG_D, None if t is None else t.data_ptr(),
+                                       None if z is None else z.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_diffusion_draw")
+    return t, z
+
+
 def dropout_keep_mask(drop_seed: torch.Tensor, task: int, drop_p: float, n: int) -> torch.Tensor:
     """The keep mask (uint8 [n, 64]) the loss kernels draw for span number `task` from `drop_seed` (int64[1] on the GPU)."""
     _vec(drop_seed, "drop_seed", torch.int64, 1)
@@ -453,28 +477,89 @@ def diffusion_loss_fwd_spans(spans: Sequence[LossSpan], target, x_start, noise, 
     return row_loss, out
 
 
+WG_ROWS_PER_PARTIAL = 128    # table rows behind one partial result of the fused weight gradients (a workgroup's rows)
+
+
+def wgrad_operand_tables(params: Sequence["DenoiserParams"], n_steps: int) -> None:
+    """The per-timestep operand table [n_steps, 16] = emb_layer(te_t) | te_t of up to two denoisers, in one launch;
+    kept on the DenoiserParams (wg_tab) for diffusion_loss_bwd_spans(fused_wgrad=True).  Depends on emb_layer only."""
+    dev = params[0].device
+    tabs = [torch.empty((n_steps, 16), dtype=torch.float32, device=dev) for _ in params]
+    dns = (C.POINTER(_lib.Denoiser) * len(params))(*[C.pointer(p.c) for p in params])
+    ptrs = (C.c_void_p * len(params))(*[t.data_ptr() for t in tabs])
+    rc = _lib.load().dg_denoiser_wgrad_tab(dns, ptrs, len(params), n_steps, _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_denoiser_wgrad_tab")
+    for p, t in zip(params, tabs):
+        p.wg_tab = t
+
+
 def diffusion_loss_bwd_spans(spans: Sequence[LossSpan], target, x_start, noise, ts, sqrt_ac, sqrt_1mac, loss_w, g_row_loss,
-                             g_out, d_target_add=None, keep_mask=None, drop_seed=None):
+                             g_out, d_target_add=None, keep_mask=None, drop_seed=None, fused_wgrad: bool = False):
     """Backward of diffusion_loss_fwd_spans in ONE launch.  d_target_add ([N,64] or None) is added into d_target.
-    Returns (d_x_start, d_target, dout_tot, hid, dpre, xn), all [N,64]."""
+    Returns (d_x_start, d_target, dout_tot, hid, dpre, xn), all [N,64] -- or, with fused_wgrad=True (every span's
+    denoiser then has its wg_tab, see wgrad_operand_tables), (d_x_start, d_target, partials): the kernel forms the
+    weight gradients' partial sums itself, partials[k] = [ceil(span k rows / 128), partial floats] for
+    denoiser_wgrad_reduce, and the four operand tables never go through memory."""
     n = x_start.shape[0]
     n_steps = loss_w.numel()
     _vec(g_row_loss, "grad of row_loss", torch.float64, n)
     for nm, t in (("grad of out", g_out), ("d_target_add", d_target_add)):
         if t is not None:
             _table(t, nm, n)
-    outs = [torch.empty_like(x_start) for _ in range(6)]
+    names = ("d_x_start", "d_target") if fused_wgrad else ("d_x_start", "d_target", "dout_tot", "hid", "dpre", "xn")
+    outs = [torch.empty_like(x_start) for _ in names]
     rb = DG_D * 4
-    names = ("d_x_start", "d_target", "dout_tot", "hid", "dpre", "xn")
     tables = {"target": (target, rb), "x_start": (x_start, rb), "noise": (noise if sqrt_ac is not None else None, rb),
               "ts": (ts, 8), "g_row_loss": (g_row_loss, 8), "g_out": (g_out, rb), "d_target_add": (d_target_add, rb)}
     tables.update({nm: (o, rb) for nm, o in zip(names, outs)})
     _check_dropout(spans, n, keep_mask, drop_seed)
     arr = _span_tasks(spans, n_steps, tables, keep_mask, drop_seed)
+    partials = []
+    if fused_wgrad:
+        pf = int(_lib.load().dg_wgrad_partial_floats())
+        for k, sp in enumerate(spans):
+            tab = getattr(sp.dn, "wg_tab", None)
+            if tab is None or tuple(tab.shape) != (n_steps, 16):
+                raise DiffGraphHipError("fused_wgrad: the span's denoiser has no operand table (wgrad_operand_tables)")
+            part = torch.empty((-(-sp.n // WG_ROWS_PER_PARTIAL), pf), dtype=torch.float32, device=x_start.device)
+            arr[k].wg_tab, arr[k].wg_partials = tab.data_ptr(), part.data_ptr()
+            partials.append(part)
     rc = _lib.load().dg_diffusion_loss_bwd_batched(arr, len(spans), n_steps, _ptr(sqrt_ac), _ptr(sqrt_1mac), loss_w.data_ptr(),
                                                    DG_D, _lib.stream_ptr(x_start.device))
     _lib.check(rc, "dg_diffusion_loss_bwd_batched")
+    if fused_wgrad:
+        return outs[0], outs[1], partials
     return tuple(outs)
+
+
+def denoiser_wgrad_reduce(jobs, launch: bool = True):
+    """The denoisers' weight gradients from the partial sums of diffusion_loss_bwd_spans(fused_wgrad=True) -- jobs:
+    (dn, partials) for up to two denoisers, one set of launches.  Returns one 6-tuple per job (d_w_emb [8,8], d_b_emb
+    [8], d_w_in [64,72], d_b_in [64], d_w_out [64,64], d_b_out [64]); with launch=False (results, go): the tensors
+    are allocated and go() launches the kernels that fill them, on the stream current at that time."""
+    lib = _lib.load()
+    arr = (_lib.WgradReduceTask * len(jobs))()
+    results, keep = [], []
+    for k, (dn, part) in enumerate(jobs):
+        dev = part.device
+        flat = torch.empty(512 + 64 + 8 + DG_D * 72 + DG_D + DG_D * DG_D + DG_D, dtype=torch.float32, device=dev)
+        parts, o = [], 512                                   # the first 512 floats: scratch of the launches
+        for shape in ((8, 8), (8,), (DG_D, 72), (DG_D,), (DG_D, DG_D), (DG_D,)):
+            m = math.prod(shape)
+            parts.append(flat[o: o + m].view(shape))
+            o += m
+        arr[k] = _lib.WgradReduceTask(C.pointer(dn.c), part.data_ptr(), part.shape[0], flat.data_ptr(), *[p.data_ptr() for p in parts])
+        keep.append((flat, part))
+        results.append(tuple(parts))
+
+    def go(_keep=keep):
+        rc = lib.dg_denoiser_wgrad_reduce(arr, len(jobs), _lib.stream_ptr(jobs[0][1].device))
+        _lib.check(rc, "dg_denoiser_wgrad_reduce")
+
+    if not launch:
+        return results, go
+    go()
+    return results
 
 
 def denoiser_wgrad(dn: DenoiserParams, n_steps: int, ts, dout, hid, dpre, xn):
@@ -483,9 +568,10 @@ def denoiser_wgrad(dn: DenoiserParams, n_steps: int, ts, dout, hid, dpre, xn):
     return denoiser_wgrad_many([(dn, ts, dout, hid, dpre, xn)], n_steps)[0]
 
 
-def denoiser_wgrad_many(jobs, n_steps: int):
+def denoiser_wgrad_many(jobs, n_steps: int, launch: bool = True):
     """denoiser_wgrad for up to two denoisers -- jobs: (dn, ts, dout, hid, dpre, xn) each -- in one set of launches.
-    Returns one 6-tuple of gradients per job."""
+    Returns one 6-tuple of gradients per job; with launch=False (results, go): the gradient tensors are allocated
+    and go() launches the kernels that fill them, on the stream current at that time."""
     lib = _lib.load()
     ws_bytes = int(lib.dg_denoiser_wgrad_workspace(n_steps))
     arr = (_lib.WgradTask * len(jobs))()
@@ -507,8 +593,13 @@ def denoiser_wgrad_many(jobs, n_steps: int):
                                 n, ws.data_ptr(), ws_bytes, *[p.data_ptr() for p in parts])
         keep.append(ws)
         results.append(tuple(parts))
-    rc = lib.dg_denoiser_wgrad_batched(arr, len(jobs), n_steps, DG_D, _lib.stream_ptr(jobs[0][2].device))
-    _lib.check(rc, "dg_denoiser_wgrad_batched")
+    def go(_keep=(keep, jobs)):
+        rc = lib.dg_denoiser_wgrad_batched(arr, len(jobs), n_steps, DG_D, _lib.stream_ptr(jobs[0][2].device))
+        _lib.check(rc, "dg_denoiser_wgrad_batched")
+
+    if not launch:
+        return results, go
+    go()
     return results
 
 

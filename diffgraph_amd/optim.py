@@ -35,7 +35,11 @@ class Adam:
         self.model.embedding_grad_parts = None
 
     def step(self) -> None:
-        self.rest.step()
+        late = getattr(self.model, "run_late_side_work", None)
+        if late is not None:    # the denoisers' gradients may be left to be formed beside the backward pass: update them there
+            late(then=self.rest.step)
+        else:
+            self.rest.step()
         parts = self.model.embedding_grad_parts
         if parts is None:
             if self.table.grad is None:

@@ -28,7 +28,12 @@ def training_step(model, opt, ancs, poss, negs, seed: torch.Tensor, draws: Optio
     be drawn inside.  Returns the four values (float64[4])."""
     res = model.cal_loss_vector(ancs, poss, negs, **(draws or {}))
     opt.zero_grad(set_to_none=True)
-    res.backward(seed)                                           # = loss.backward()
+    # the denoisers' weight gradients may be formed beside the propagation's backward pass: opt.step() waits for them
+    model.side_join_deferred = isinstance(opt, Adam)
+    try:
+        res.backward(seed)                                       # = loss.backward()
+    finally:
+        model.side_join_deferred = False
     opt.step()
     return res
 
@@ -89,16 +94,17 @@ class Coach:
         o = self.opt
         return ([p.detach().clone() for p in self.model.parameters()], o.exp_avg.clone(), o.exp_avg_sq.clone(), o.state.clone(),
                 {p: {k: v.clone() for k, v in st.items()} for p, st in o.rest.state.items()}, self._sums.clone(),
-                self._batch_no.clone(), None if self._draw_no is None else self._draw_no.clone())
+                self._batch_no.clone(), None if self._draw_no is None else self._draw_no.clone(), self.model.draw_state.clone())
 
     def _restore(self, snap) -> None:
         """Puts the values back IN PLACE: the recorded graph holds the addresses of these tensors."""
-        params, m, v, state, rest, sums, batch_no, draw_no = snap
+        params, m, v, state, rest, sums, batch_no, draw_no, draw_state = snap
         o = self.opt
         with torch.no_grad():
             for p, q in zip(self.model.parameters(), params):
                 p.copy_(q)
             o.exp_avg.copy_(m); o.exp_avg_sq.copy_(v); o.state.copy_(state); self._sums.copy_(sums); self._batch_no.copy_(batch_no)
+            self.model.draw_state.copy_(draw_state)
             if draw_no is not None:
                 self._draw_no.copy_(draw_no)
             for p, st in o.rest.state.items():      # moments the warm-up steps created start from zero

@@ -309,7 +309,21 @@ typedef struct dg_loss_task {
   const uint8_t *keep_mask;
   const int64_t *drop_seed;
   float drop_p;
+  /* Backward only.  wg_partials != NULL: the kernel forms the weight gradients' partial sums itself, one partial
+   * result of dg_wgrad_partial_floats() floats per 128 rows ((n + 127) / 128 of them, every one written whole),
+   * for dg_denoiser_wgrad_reduce; dout_tot / hid / dpre / xn are then not written and may be NULL.  wg_tab: the
+   * denoiser's operand table from dg_denoiser_wgrad_tab ([n_steps][16]). */
+  const float *wg_tab;
+  float *wg_partials;
 } dg_loss_task;
+
+/* The random inputs of one training_losses2 call (t.randint(0, steps, (batch,)) and t.randn_like(x_start),
+ * DiffGraph-Rec/Model.py:352-353) for n rows: ts int64[n] uniform in [0, n_steps), noise fp32 [n][64] standard
+ * normal (either may be NULL).  state: int64[4] on the device = {seed, draws made so far, key of this draw's
+ * dropout masks, spare}; the draw is a function of (seed, draws made) alone, the call then increments state[1] and
+ * writes state[2] (dg_loss_task.drop_seed may point at it) -- all on the device, so a recorded step draws anew on
+ * every replay.  The streams are not torch's: only the distribution is the reference's. */
+int dg_diffusion_draw(int64_t *state, int64_t n, int32_t n_steps, int32_t d, int64_t *ts, float *noise, void *stream);
 
 /* The keep mask (uint8 [n][64], 1 = kept) the loss entry points draw for task number `task` from *drop_seed. */
 int dg_dropout_keep_mask(const int64_t *drop_seed, int32_t task, float drop_p, int64_t n, int32_t d, uint8_t *mask,
@@ -363,6 +377,22 @@ typedef struct dg_wgrad_task {
 } dg_wgrad_task;
 int dg_denoiser_wgrad_batched(const dg_wgrad_task *tasks, int32_t n_tasks, int32_t n_steps, int32_t d,
                               void *stream);
+
+/* The same gradients without the four operand tables going through memory: dg_diffusion_loss_bwd_batched forms
+ * the partial sums (dg_loss_task.wg_partials / wg_tab) and dg_denoiser_wgrad_reduce adds them up in partial order
+ * (the same bits on every run) and finishes emb_layer's gradients.
+ * dg_denoiser_wgrad_tab: the per-timestep operand table [n_steps][16] = emb_layer(te_t) | te_t of up to two
+ * denoisers (depends on emb_layer's weights only).  mk: DEVICE scratch of 512 floats per task. */
+int64_t dg_wgrad_partial_floats(void);
+int dg_denoiser_wgrad_tab(const dg_denoiser *const *dns, float *const *tabs, int32_t n_tabs, int32_t n_steps, void *stream);
+typedef struct dg_wgrad_reduce_task {
+  const dg_denoiser *dn;
+  const float *partials;
+  int32_t n_partials;
+  float *mk;
+  float *d_w_emb, *d_b_emb, *d_w_in, *d_b_in, *d_w_out, *d_b_out;
+} dg_wgrad_reduce_task;
+int dg_denoiser_wgrad_reduce(const dg_wgrad_reduce_task *tasks, int32_t n_tasks, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * a10: the loss head of HGDM.cal_loss (DiffGraph-Rec/Model.py:101-111; pairPredict,

@@ -140,6 +140,47 @@ def test_mask_drawn_in_the_kernel_equals_the_mask_supplied():
         ops.diffusion_loss_fwd_spans(spans, target, x0, noise, ts, sa, sb, lw)      # dropout on, neither mask nor seed
 
 
+def test_device_side_draws_of_timesteps_and_noise():
+    """ops.diffusion_draw stands in for t.randint(0, steps, (batch,)) and t.randn_like(x_start) (Model.py:352-353): a
+    function of (seed, draws made so far) alone, uniform timesteps, standard-normal noise with independent entries;
+    the streams are not torch's, so the distribution is what is checked."""
+    from scipy import stats
+    n, steps = 40000, 200
+    st = ops.new_draw_state(DEV, seed=77)
+    ts, z = ops.diffusion_draw(st, n, steps)
+    torch.cuda.synchronize()
+    assert st.tolist()[:2] == [77, 1] and st.tolist()[2] > 0
+    key1 = int(st[2])
+    ts2, z2 = ops.diffusion_draw(st, n, steps)
+    assert st.tolist()[:2] == [77, 2] and int(st[2]) != key1
+    assert not torch.equal(ts, ts2) and not torch.equal(z, z2)
+    st_b = ops.new_draw_state(DEV, seed=77)
+    ts_b, z_b = ops.diffusion_draw(st_b, n, steps)
+    assert torch.equal(ts, ts_b) and torch.equal(z, z_b) and int(st_b[2]) == key1       # same state, same draw
+    only_t, none_z = ops.diffusion_draw(st_b, n, steps, noise=False)                    # the second draw, timesteps only
+    assert none_z is None and torch.equal(only_t, ts2)
+    ts_c, _ = ops.diffusion_draw(ops.new_draw_state(DEV, seed=78), n, steps)
+    assert not torch.equal(ts, ts_c)
+    # timesteps: in range, uniform (chi-square over the 200 values)
+    t = ts.cpu().numpy()
+    assert t.min() == 0 and t.max() == steps - 1
+    chi2 = ((np.bincount(t, minlength=steps) - n / steps) ** 2 / (n / steps)).sum()
+    assert chi2 < steps + 5 * np.sqrt(2 * steps)
+    # noise: moments, a Kolmogorov-Smirnov test against N(0,1), no correlation between neighbours in a row, a column,
+    # the two halves of a Box-Muller pair, or successive draws
+    v = z.double().cpu().numpy()
+    m = v.size
+    assert abs(v.mean()) < 5 / np.sqrt(m) and abs(v.var() - 1) < 5 * np.sqrt(2 / m)
+    assert abs((v ** 4).mean() - 3) < 5 * np.sqrt(96 / m) and abs((v ** 3).mean()) < 5 * np.sqrt(15 / m)
+    assert stats.kstest(v.ravel()[:: 7], "norm").pvalue > 1e-3
+    assert np.abs(v).max() > 4.5          # the tails are there (2.56 M draws) ...
+    assert np.abs(v).max() < 5.8          # ... up to the 24-bit uniforms' limit, sqrt(2 ln 2^24) = 5.77
+    corr = lambda a, b: abs((a * b).mean()) * np.sqrt(a.size)
+    assert corr(v[:, :-1], v[:, 1:]) < 5 and corr(v[:-1], v[1:]) < 5 and corr(v[:, 0::2], v[:, 1::2]) < 5
+    assert corr(v, z2.double().cpu().numpy()) < 5
+    assert corr(v[:, 0] , t - (steps - 1) / 2) / np.sqrt((steps ** 2 - 1) / 12) < 5
+
+
 def test_model_in_train_mode_draws_fresh_masks():
     fx, nu, ni, *_ = tiny_fixture()
     m = rec_model(dgdata.rec_workload("tiny"), fx).train()

@@ -330,6 +330,43 @@ def test_denoiser_weight_gradients_two_denoisers_one_call():
         ops.denoiser_wgrad_many(jobs + jobs[:1], T_)
 
 
+@pytest.mark.parametrize("n_u,n_i,drop", [(1, 1, 0.0), (127, 129, 0.0), (128, 256, 0.5), (5000, 3333, 0.5)])
+def test_weight_gradients_formed_inside_the_loss_backward(n_u, n_i, drop):
+    """diffusion_loss_bwd_spans(fused_wgrad=True) + denoiser_wgrad_reduce -- the weight gradients' operands summed by
+    the loss backward kernel itself, per 128-row strip -- against the path through the four operand tables
+    (denoiser_wgrad_many): the other outputs are the same bits, the gradients agree to fp32 summation order (the strips
+    differ), and they are the same bits on every run."""
+    gen = torch.Generator().manual_seed(n_u)
+    n, n_steps = n_u + n_i, 200
+    gd = dg.GaussianDiffusion(**REC_TABLE)
+    dns = [dg.Denoise([64, 64], [64, 64], 8, norm=True).to(DEV) for _ in range(2)]
+    spans = [ops.LossSpan(dns[0].params(True), 0, n_u, drop), ops.LossSpan(dns[1].params(True), n_u, n_i, drop)]
+    ops.refresh_time_bias([sp.dn for sp in spans], n_steps)
+    ops.wgrad_operand_tables([sp.dn for sp in spans], n_steps)
+    target, x0, noise = (dev(torch.randn(n, 64, generator=gen)) for _ in range(3))
+    ts = dev(torch.randint(0, n_steps, (n,), generator=gen))
+    sa, sb = gd._dev("sqrt_alphas_cumprod", DEV), gd._dev("sqrt_one_minus_alphas_cumprod", DEV)
+    lw = gd._dev("loss_weight", DEV, torch.float64)
+    g_row, g_out, add = dev(torch.rand(n, generator=gen).double()), dev(torch.randn(n, 64, generator=gen)), dev(torch.randn(n, 64, generator=gen))
+    keep = dev((torch.rand(n, 64, generator=gen) >= drop).to(torch.uint8)) if drop else None
+    args = (spans, target, x0, noise, ts, sa, sb, lw, g_row, g_out)
+    d_x, d_t, dout, hid, dpre, xn = ops.diffusion_loss_bwd_spans(*args, d_target_add=add, keep_mask=keep)
+    want = ops.denoiser_wgrad_many([(sp.dn,) + tuple(t[sp.begin: sp.begin + sp.n] for t in (ts, dout, hid, dpre, xn))
+                                    for sp in spans], n_steps)
+    d_x2, d_t2, partials = ops.diffusion_loss_bwd_spans(*args, d_target_add=add, keep_mask=keep, fused_wgrad=True)
+    assert torch.equal(d_x, d_x2) and torch.equal(d_t, d_t2)
+    assert [p.shape[0] for p in partials] == [-(-n_u // 128), -(-n_i // 128)]
+    got = ops.denoiser_wgrad_reduce([(sp.dn, p) for sp, p in zip(spans, partials)])
+    _, _, partials_b = ops.diffusion_loss_bwd_spans(*args, d_target_add=add, keep_mask=keep, fused_wgrad=True)
+    again = ops.denoiser_wgrad_reduce([(sp.dn, p) for sp, p in zip(spans, partials_b)])
+    for k in range(2):
+        for nm, g, g2, w in zip(("w_emb", "b_emb", "w_in", "b_in", "w_out", "b_out"), got[k], again[k], want[k]):
+            assert torch.equal(g, g2), nm
+            assert_close_to_max(g, w, 1e-5, f"fused grad {k} {nm}")
+    if n_u <= 128 and n_i <= 128:      # one strip per denoiser
+        assert all(p.shape[0] == 1 for p in partials)
+
+
 @pytest.mark.parametrize("n_batch,nu,ni", [(1, 50, 70), (37, 50, 70), (2048, 50, 70), (8192, 50, 70), (8192, 300, 500),
                                           (2048, 3000, 40)])
 def test_rec_loss_head_matches_torch_autograd(n_batch, nu, ni):

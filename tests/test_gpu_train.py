@@ -91,11 +91,13 @@ def _optimizer_state(o):
     return out
 
 
+@pytest.mark.parametrize("draws", ["given", "drawn"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_replayed_steps_equal_eager_steps_bit_for_bit(mode):
+def test_replayed_steps_equal_eager_steps_bit_for_bit(mode, draws):
     """The step Coach replays as a HIP graph (full batch and the epoch's short last batch) against the same step
-    launched eagerly, with the timesteps, the noise and (train mode) the dropout masks of every step fixed: the epoch
-    losses, every parameter and the optimizer's moments are the same bits after two epochs."""
+    launched eagerly: the epoch losses, every parameter and the optimizer's moments are the same bits after two
+    epochs -- with the timesteps, the noise and (train mode) the dropout masks of every step handed in, and with
+    the step drawing them itself from the model's device-side draw state (same seed: same draws, replayed or not)."""
     args = _args(64)
     coaches = {}
     for use_graph in (True, False):
@@ -103,7 +105,9 @@ def test_replayed_steps_equal_eager_steps_bit_for_bit(mode):
         c = Coach(_handler(), args, device=DEV, use_graph=use_graph, seed=3)
         c.prepareModel()
         c.model.train(mode == "train")
-        _fixed_draws(c, 16, seed=21, keep=mode == "train")
+        if draws == "given":
+            _fixed_draws(c, 16, seed=21, keep=mode == "train")
+        assert c.model.draw_state.tolist() == [9, 0, 0, 0]
         if use_graph:
             before = [p.detach().clone() for p in c.model.parameters()]
             c._capture(64)
@@ -111,11 +115,15 @@ def test_replayed_steps_equal_eager_steps_bit_for_bit(mode):
                 assert torch.equal(p, q)
             o = c.opt
             assert not o.exp_avg.any() and not o.exp_avg_sq.any() and not o.state.any() and not c._sums.any()
-            assert int(c._draw_no) == 0 and int(c._batch_no) == 0
+            assert int(c._batch_no) == 0 and (draws == "drawn" or int(c._draw_no) == 0)
+            assert c.model.draw_state.tolist() == [9, 0, 0, 0]
         coaches[use_graph] = (c, [c.trainEpoch() for _ in range(2)])
     (g, g_res), (e, e_res) = coaches[True], coaches[False]
     assert sorted(g._graphs) == [(58, mode == "train"), (64, mode == "train")]      # 186 pairs: 64 + 64 + 58
-    assert int(g._draw_no) == int(e._draw_no) == 6
+    if draws == "given":
+        assert int(g._draw_no) == int(e._draw_no) == 6
+    assert int(g.model.draw_state[1]) == int(e.model.draw_state[1]) == (6 if draws == "drawn" else 0)
+    assert torch.equal(g.model.draw_state, e.model.draw_state)
     for a, b in zip(g_res, e_res):
         assert np.isfinite(a["Loss"])
         assert a == b, (a, b)
