@@ -140,7 +140,11 @@ SIGNATURES = {
     "dg_spgemm_pattern_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dg_adam_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "dg_adam_step_prepared": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dg_rec_head_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 4),
+    "dg_rec_head_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "dg_adam_prepare": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "dg_rec_head_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 10),
 }
 

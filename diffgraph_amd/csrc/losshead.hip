@@ -267,12 +267,23 @@ extern "C" int dg_rec_head_fwd(const float *ui, const float *out_u, const float 
                                int32_t n_batch, int32_t n_user, int32_t n_item, double batch_div, double reg_coef,
                                int32_t d, float *entries_f, double *entries_d, double *results, void *stream) {
   if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_rec_head_fwd: embedding width %d unsupported (built for %d)", d, DG_D);
-  if (!ui || !out_u || !out_i || !row_loss_u || !row_loss_i || !ancs || !poss || !negs || !entries_f || !entries_d || !results)
+  if (!ui || !out_u || !out_i || !row_loss_u || !row_loss_i || !ancs || !poss || !negs || !entries_f || !entries_d)
     return dg_fail(DG_ERR_ARG, "dg_rec_head_fwd: NULL argument");
   if (n_batch <= 0 || n_batch > kMaxBatch) return dg_fail(DG_ERR_SIZE, "dg_rec_head_fwd: n_batch must be in [1,%d] (got %d)", kMaxBatch, n_batch);
   if (n_user <= 0 || n_item <= 0 || batch_div == 0.0) return dg_fail(DG_ERR_ARG, "dg_rec_head_fwd: bad sizes");
   hipLaunchKernelGGL(head_fwd_kernel, dim3((n_batch + 15) / 16), dim3(256), 0, (hipStream_t)stream, ui, out_u, out_i,
                      row_loss_u, row_loss_i, ancs, poss, negs, n_batch, n_user, n_item, entries_f, entries_d);
+  if (results)
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, entries_f, entries_d, n_batch, batch_div,
+                       reg_coef, results);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dg_rec_head_reduce(const float *entries_f, const double *entries_d, int32_t n_batch, double batch_div,
+                                  double reg_coef, double *results, void *stream) {
+  if (!entries_f || !entries_d || !results) return dg_fail(DG_ERR_ARG, "dg_rec_head_reduce: NULL argument");
+  if (n_batch <= 0 || n_batch > kMaxBatch || batch_div == 0.0) return dg_fail(DG_ERR_SIZE, "dg_rec_head_reduce: bad sizes");
   hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, entries_f, entries_d, n_batch, batch_div,
                      reg_coef, results);
   DG_HIP(hipGetLastError());

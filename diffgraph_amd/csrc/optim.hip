@@ -60,9 +60,16 @@ __global__ __launch_bounds__(256) void adam_table_kernel(const adam_args a) {
 
 }  // namespace
 
-extern "C" int dg_adam_step(float *param, const float *const *grad_parts_host, int32_t n_parts, float *exp_avg,
-                            float *exp_avg_sq, float *state, int64_t n_elems, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, void *stream) {
+extern "C" int dg_adam_prepare(float *state, float beta1, float beta2, void *stream) {
+  if (!state) return dg_fail(DG_ERR_ARG, "dg_adam_prepare: NULL argument");
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+static int adam_step(float *param, const float *const *grad_parts_host, int32_t n_parts, float *exp_avg, float *exp_avg_sq,
+                     float *state, int64_t n_elems, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     bool prepare, void *stream) {
   if (!param || !grad_parts_host || !exp_avg || !exp_avg_sq || !state) return dg_fail(DG_ERR_ARG, "dg_adam_step: NULL argument");
   if (n_parts < 1 || n_parts > kMaxParts) return dg_fail(DG_ERR_ARG, "dg_adam_step: n_parts must be in [1,%d]", kMaxParts);
   if (n_elems < 0 || n_elems % 4 != 0) return dg_fail(DG_ERR_ARG, "dg_adam_step: element count must be a multiple of 4");
@@ -75,10 +82,24 @@ extern "C" int dg_adam_step(float *param, const float *const *grad_parts_host, i
   if (((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return dg_fail(DG_ERR_ARG, "dg_adam_step: tables must be 16-byte aligned");
   a.n_parts = n_parts; a.param = param; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.state = state;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.n4 = n_elems / 4;
-  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
+  if (prepare) hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
   int64_t blocks = (a.n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_table_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   DG_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int dg_adam_step(float *param, const float *const *grad_parts_host, int32_t n_parts, float *exp_avg,
+                            float *exp_avg_sq, float *state, int64_t n_elems, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, void *stream) {
+  return adam_step(param, grad_parts_host, n_parts, exp_avg, exp_avg_sq, state, n_elems, lr, beta1, beta2, eps, weight_decay,
+                   true, stream);
+}
+
+extern "C" int dg_adam_step_prepared(float *param, const float *const *grad_parts_host, int32_t n_parts, float *exp_avg,
+                                     float *exp_avg_sq, float *state, int64_t n_elems, float lr, float beta1, float beta2,
+                                     float eps, float weight_decay, void *stream) {
+  return adam_step(param, grad_parts_host, n_parts, exp_avg, exp_avg_sq, state, n_elems, lr, beta1, beta2, eps, weight_decay,
+                   false, stream);
 }

@@ -121,8 +121,14 @@ class _RecLossFn(torch.autograd.Function):
         lw = gd._dev("loss_weight", dev, torch.float64)
         row_loss, out = ops.diffusion_loss_fwd_spans(spans, ui, het, noise, ts, sa, sb, lw, validate=validate,
                                                      keep_mask=keep_mask, drop_seed=drop_seed)
-        results, ent_f = ops.rec_head_fwd(ui, out[:nu], out[nu:], row_loss[:nu], row_loss[nu:], ancs, poss, negs, nu,
-                                          float(args.batch), float(args.reg))
+        # (a caller that joins the side stream before it reads the four values -- training_step -- gets them from there)
+        if model.side_join_deferred:
+            results, ent_f, go = ops.rec_head_fwd(ui, out[:nu], out[nu:], row_loss[:nu], row_loss[nu:], ancs, poss, negs, nu,
+                                                  float(args.batch), float(args.reg), reduce_later=True)
+            model._late_side.append((model.fork_point(), go))
+        else:
+            results, ent_f = ops.rec_head_fwd(ui, out[:nu], out[nu:], row_loss[:nu], row_loss[nu:], ancs, poss, negs, nu,
+                                              float(args.batch), float(args.reg))
         ctx.save_for_backward(ui, het, noise if noise is not None else het, ts, out, ancs, poss, negs, ent_f)
         ctx.aux = (model, spans, sa, sb, lw, keep_mask, drop_seed)
         return results
@@ -132,8 +138,9 @@ class _RecLossFn(torch.autograd.Function):
         ui, het, noise, ts, out, ancs, poss, negs, ent_f = ctx.saved_tensors
         model, spans, sa, sb, lw, keep_mask, drop_seed = ctx.aux
         gd, args, nu = model.diffusion_process, model.args, model.n_user
+        head_buf, model._head_buf = model._head_buf, None     # cleared beside the forward propagation (cal_loss_vector)
         d_ui_head, d_out, d_rl = ops.rec_head_bwd(ui, out[:nu], out[nu:], ancs, poss, negs, nu, float(args.batch),
-                                                  float(args.reg), ent_f, g.contiguous(), full=True)
+                                                  float(args.reg), ent_f, g.contiguous(), full=True, buffer=head_buf)
         # one launch for both diffusion losses; it also sums the weight gradients' operands over its 128-row strips
         d_het, d_ui, partials = ops.diffusion_loss_bwd_spans(spans, ui, het, noise, ts, sa, sb, lw, d_rl, d_out,
                                                              d_target_add=d_ui_head, keep_mask=keep_mask,
@@ -143,7 +150,7 @@ class _RecLossFn(torch.autograd.Function):
             # a caller that promises run_late_side_work() before it touches the gradients (training_step): the strips'
             # sums are added up after the propagation's backward pass is launched and beside it, from here on
             res, go = ops.denoiser_wgrad_reduce(jobs, launch=False)
-            model._late_side = (model.fork_point(), go)
+            model._late_side.append((model.fork_point(), go))
         else:
             res = ops.denoiser_wgrad_reduce(jobs)               # both denoisers, one set of launches
         grads = [g for r in res for g in r]
@@ -179,7 +186,8 @@ class HGDM(nn.Module):
         self.register_buffer("draw_state", ops.new_draw_state(device), persistent=False)
         self._side: Optional[torch.cuda.Stream] = None
         self._side_pending: list = []
-        self._late_side = None
+        self._late_side: list = []
+        self._head_buf: Optional[torch.Tensor] = None
         self.side_join_deferred = False
 
     # -- work beside the main stream --------------------------------------------------------------------
@@ -217,11 +225,13 @@ class HGDM(nn.Module):
     def run_late_side_work(self, then=None) -> None:
         """Launches what a backward pass under side_join_deferred left for later (and `then`, e.g. the update of the
         parameters whose gradients it forms) on the side stream, and joins."""
-        if self._late_side is not None:
-            after, go = self._late_side
-            self._late_side = None
-            with self.side_work(after=after):
-                go()
+        late, self._late_side = self._late_side, []
+        if late:
+            # one fork for all of them, behind the last one's fork point (every dependency between the two streams
+            # costs the main chain a few microseconds)
+            with self.side_work(after=late[-1][0]):
+                for _, go in late:
+                    go()
                 if then is not None:
                     then()
         elif then is not None:
@@ -313,6 +323,7 @@ class HGDM(nn.Module):
         noise = None
         if dp.noise_scale != 0:
             noise = torch.empty((n, DG_D), device=dev) if need_noise else torch.cat([noise_u, noise_i]).contiguous()
+        self._head_buf = ops.rec_head_bwd_buffer(n, dev, clear=False) if torch.is_grad_enabled() else None
         start = self.fork_point()
         ui, het = self.propagate(self.embedding_table)   # [users | items] tables: target-graph sums, behaviour sums
         # beside the propagation (launched after it, started before it): the draws and both denoisers' time-bias tables
@@ -324,6 +335,7 @@ class HGDM(nn.Module):
             ops.refresh_time_bias(params, dp.steps)
             if torch.is_grad_enabled():
                 ops.wgrad_operand_tables(params, dp.steps)     # the backward pass's time-embedding operands
+                ops.clear_rec_head_bwd_buffer(self._head_buf, n)   # ... and the loss head's cleared gradient tables
         self.join_side_work()
         drop = dropout_args(denoisers, keep, dev, self.draw_state[2:3])
         ancs, poss, negs = (v.long().contiguous() for v in (ancs, poss, negs))

@@ -609,9 +609,12 @@ def _index_vec(v: torch.Tensor, name: str, n: int) -> None:
         raise DiffGraphHipError(f"{name}: expected a contiguous int64 GPU vector of {n} elements")
 
 
-def rec_head_fwd(ui, out_u, out_i, row_loss_u, row_loss_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float):
+def rec_head_fwd(ui, out_u, out_i, row_loss_u, row_loss_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float,
+                 reduce_later: bool = False):
     """Loss head of HGDM.cal_loss (Model.py:101-111).  Returns (results fp64[4] = loss, bpr, reg, diff; entries_f).
-    out_u / out_i and row_loss_u / row_loss_i may be the two row spans of one table."""
+    out_u / out_i and row_loss_u / row_loss_i may be the two row spans of one table.  reduce_later=True returns
+    (results, entries_f, go): the last launch -- the sums over the batch entries, which nothing of the backward pass
+    reads -- is left to go(), on the stream current at that time; results are valid after it."""
     n_item = ui.shape[0] - n_user
     B = ancs.numel()
     _table(ui, "ui")
@@ -625,26 +628,48 @@ def rec_head_fwd(ui, out_u, out_i, row_loss_u, row_loss_i, ancs, poss, negs, n_u
     ent_d = torch.empty(2 * B + 4, dtype=torch.float64, device=dev)   # per-entry diffusion losses, then the results
     ent_f = torch.empty(8 * B, dtype=torch.float32, device=dev)
     results = ent_d[2 * B:]
-    rc = _lib.load().dg_rec_head_fwd(ui.data_ptr(), out_u.data_ptr(), out_i.data_ptr(), row_loss_u.data_ptr(),
-                                     row_loss_i.data_ptr(), ancs.data_ptr(), poss.data_ptr(), negs.data_ptr(), B, n_user,
-                                     n_item, float(batch_div), float(reg), DG_D, ent_f.data_ptr(), ent_d.data_ptr(),
-                                     results.data_ptr(), _lib.stream_ptr(dev))
+    lib = _lib.load()
+    rc = lib.dg_rec_head_fwd(ui.data_ptr(), out_u.data_ptr(), out_i.data_ptr(), row_loss_u.data_ptr(),
+                             row_loss_i.data_ptr(), ancs.data_ptr(), poss.data_ptr(), negs.data_ptr(), B, n_user,
+                             n_item, float(batch_div), float(reg), DG_D, ent_f.data_ptr(), ent_d.data_ptr(),
+                             None if reduce_later else results.data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "dg_rec_head_fwd")
+    if reduce_later:
+        def go(_keep=(ent_f, ent_d)):
+            rc = lib.dg_rec_head_reduce(ent_f.data_ptr(), ent_d.data_ptr(), B, float(batch_div), float(reg), results.data_ptr(),
+                                        _lib.stream_ptr(dev))
+            _lib.check(rc, "dg_rec_head_reduce")
+        return results, ent_f, go
     return results, ent_f
 
 
-def rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float, ent_f, g, full: bool = False):
+def rec_head_bwd_buffer(n: int, device, clear: bool = True) -> torch.Tensor:
+    """The buffer rec_head_bwd writes its five outputs and the per-row tags into (every part 16-byte aligned);
+    all but the last 24 n bytes (entry slots) have to be zero when it is handed over -- clear=False leaves that to
+    the caller (clear_rec_head_bwd_buffer, e.g. on another stream ahead of time)."""
+    buf = torch.empty(2 * n * DG_D * 4 + 40 * n, dtype=torch.uint8, device=device)
+    if clear:
+        clear_rec_head_bwd_buffer(buf, n)
+    return buf
+
+
+def clear_rec_head_bwd_buffer(buf: torch.Tensor, n: int) -> None:
+    buf[: 2 * n * DG_D * 4 + 16 * n].zero_()
+
+
+def rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float, ent_f, g, full: bool = False,
+                 buffer: Optional[torch.Tensor] = None):
     """Backward of rec_head_fwd; g: fp64[4] upstream gradients.  Returns dense (d_ui, d_out_u, d_out_i,
     d_row_loss_u, d_row_loss_i), zero outside the batch rows; with full=True (d_ui, d_out [N,64], d_row_loss [N])
-    -- the user and item parts as one table each."""
+    -- the user and item parts as one table each.  buffer: a cleared rec_head_bwd_buffer(n) to use."""
     n, n_item = ui.shape[0], ui.shape[0] - n_user
     B = ancs.numel()
     _vec(g, "upstream gradients", torch.float64, 4)
     dev = ui.device
-    # one cleared buffer for the five outputs and the per-row tags, every part 16-byte aligned
     tb = n * DG_D * 4
-    zero = torch.empty(2 * tb + 40 * n, dtype=torch.uint8, device=dev)   # ... the last 24 n bytes (entry slots) stay as they are
-    zero[: 2 * tb + 16 * n].zero_()
+    zero = rec_head_bwd_buffer(n, dev) if buffer is None else buffer
+    if zero.numel() != 2 * tb + 40 * n or zero.dtype != torch.uint8 or zero.device != dev:
+        raise DiffGraphHipError("rec_head_bwd: buffer is not a rec_head_bwd_buffer of this table size")
     d_ui = zero[:tb].view(torch.float32).view(n, DG_D)
     d_out = zero[tb: 2 * tb].view(torch.float32).view(n, DG_D)
     d_rl = zero[2 * tb: 2 * tb + 8 * n].view(torch.float64)

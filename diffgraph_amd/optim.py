@@ -35,23 +35,31 @@ class Adam:
         self.model.embedding_grad_parts = None
 
     def step(self) -> None:
+        parts = self.model.embedding_grad_parts
+        if parts is None and self.table.grad is not None:
+            parts = [self.table.grad]
+        lib = _lib.load()
+
+        def small():    # the denoisers' update, and the table's step count and bias corrections
+            self.rest.step()
+            if parts is not None:
+                _lib.check(lib.dg_adam_prepare(self.state.data_ptr(), self.betas[0], self.betas[1], _lib.stream_ptr(self.table.device)),
+                           "dg_adam_prepare")
+
         late = getattr(self.model, "run_late_side_work", None)
         if late is not None:    # the denoisers' gradients may be left to be formed beside the backward pass: update them there
-            late(then=self.rest.step)
+            late(then=small)
         else:
-            self.rest.step()
-        parts = self.model.embedding_grad_parts
+            small()
         if parts is None:
-            if self.table.grad is None:
-                return
-            parts = [self.table.grad]
+            return
         parts = [p.contiguous() for p in parts]
         arr = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
         t = self.table.data
-        rc = _lib.load().dg_adam_step(t.data_ptr(), arr, len(parts), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                      self.state.data_ptr(), t.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
-                                      self.weight_decay, _lib.stream_ptr(t.device))
-        _lib.check(rc, "dg_adam_step")
+        rc = lib.dg_adam_step_prepared(t.data_ptr(), arr, len(parts), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                       self.state.data_ptr(), t.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                       self.weight_decay, _lib.stream_ptr(t.device))
+        _lib.check(rc, "dg_adam_step_prepared")
 
     def state_dict(self) -> Dict:
         return {"table": {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "state": self.state}, "rest": self.rest.state_dict(),

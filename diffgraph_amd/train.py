@@ -26,11 +26,13 @@ def training_step(model, opt, ancs, poss, negs, seed: torch.Tensor, draws: Optio
     vector [1, 0, 0, 0] = d loss / d (loss, bprLoss, regLoss, diff_loss).  `draws`: the step's random inputs as
     keyword arguments of HGDM.cal_loss_vector (ts_u, noise_u, ts_i, noise_i, keep_u, keep_i) when they are not to
     be drawn inside.  Returns the four values (float64[4])."""
-    res = model.cal_loss_vector(ancs, poss, negs, **(draws or {}))
-    opt.zero_grad(set_to_none=True)
-    # the denoisers' weight gradients may be formed beside the propagation's backward pass: opt.step() waits for them
+    # What nothing on the way to the table's update waits for -- the sums of the four loss values, the denoisers'
+    # weight gradients and their Adam step -- may run beside the propagation: opt.step() joins before it returns.
     model.side_join_deferred = isinstance(opt, Adam)
+    model._late_side = []            # (nothing of an abandoned step)
     try:
+        res = model.cal_loss_vector(ancs, poss, negs, **(draws or {}))
+        opt.zero_grad(set_to_none=True)
         res.backward(seed)                                       # = loss.backward()
     finally:
         model.side_join_deferred = False

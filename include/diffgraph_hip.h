@@ -415,6 +415,10 @@ int dg_rec_head_fwd(const float *ui, const float *out_u, const float *out_i, con
                     const int64_t *negs, int32_t n_batch, int32_t n_user, int32_t n_item,
                     double batch_div, double reg_coef, int32_t d, float *entries_f,
                     double *entries_d, double *results, void *stream);
+/* results == NULL above leaves out the last launch (the sums over the entries); dg_rec_head_reduce is that launch
+ * alone -- the backward call needs the entries only, so the sums may run beside it on another stream. */
+int dg_rec_head_reduce(const float *entries_f, const double *entries_d, int32_t n_batch, double batch_div,
+                       double reg_coef, double *results, void *stream);
 
 /* Backward of dg_rec_head_fwd.  g: DEVICE fp64[4] = dL/d{loss,bpr,reg,diff} (what autograd hands
  * back; usually {1,0,0,0}).  Writes the dense gradient tables d_ui [n_user+n_item][64],
@@ -443,6 +447,12 @@ int dg_rec_head_bwd(const float *ui, const float *out_u, const float *out_i, con
 int dg_adam_step(float *param, const float *const *grad_parts_host, int32_t n_parts, float *exp_avg,
                  float *exp_avg_sq, float *state, int64_t n_elems, float lr, float beta1, float beta2,
                  float eps, float weight_decay, void *stream);
+/* The same in two calls, so that the first (one thread: the step count and the two bias corrections of the step
+ * to come) can be issued early, on another stream: dg_adam_prepare, then dg_adam_step_prepared ordered after it. */
+int dg_adam_prepare(float *state, float beta1, float beta2, void *stream);
+int dg_adam_step_prepared(float *param, const float *const *grad_parts_host, int32_t n_parts, float *exp_avg,
+                          float *exp_avg_sq, float *state, int64_t n_elems, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * All-rank evaluation.  Replaces the per-batch body of Coach.testEpoch
