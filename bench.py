@@ -353,11 +353,15 @@ def main():
     # Kernel-level timing for the roofline, in this same process: HIP events around each fused layer launch of (a) the
     # step just timed, launched eagerly (events cannot be read back from inside a replayed graph; the kernels and
     # their arguments are the same), and (b) the inference-mode propagation (HGDM.predict's), back to back.
+    # The timed step runs its short side launches (random draws, time-bias tables, buffer clearing) BESIDE the first
+    # layer launch; here they stay in line on the one stream, so that an interval holds the layer kernels alone.
     timer.enabled = True
+    model.side_overlap = False
     for _ in range(max(args.steps // 2, 10)):
         torch.cuda._sleep(10_000_000)   # the GPU spins ~5 ms while the host queues the step: launches then run back to back,
         step()                          # and an interval holds kernel time, not the host's launch latency
     torch.cuda.synchronize()
+    model.side_overlap = True
     train_layers = timer.by_key()
     timer.records = []
     with torch.no_grad():
@@ -405,7 +409,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "gcn_layer_kernel + hub_reduce_kernel (one fused propagation layer, all graphs; mean over the "
-                               "forward layer launches of the training step)",
+                               "forward layer launches of the training step, timed with nothing running beside them -- in the "
+                               "replayed step the first one shares the GPU with the step's short side launches and takes "
+                               "about 10 % longer, see the step timeline under profiles/)",
                      "bytes_per_launch": layer_bytes_algo, "ms_per_launch": layer_ms,
                      "bytes_compulsory": comp_mean, "frac_compulsory": comp_mean / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "per_layer": per_layer},

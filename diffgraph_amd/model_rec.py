@@ -189,6 +189,7 @@ class HGDM(nn.Module):
         self._late_side: list = []
         self._head_buf: Optional[torch.Tensor] = None
         self.side_join_deferred = False
+        self.side_overlap = True       # False: side_work() stays on the current stream (one kernel at a time, e.g. to time them)
 
     # -- work beside the main stream --------------------------------------------------------------------
     # The propagation kernels wait on memory most of the time; short launches that do not depend on them (the
@@ -212,6 +213,9 @@ class HGDM(nn.Module):
         """Runs the block on the side stream, after everything launched so far on the current one (or up to the
         fork_point `after`).  The current stream does not wait for it until join_side_work(); `keep` holds what the
         block reads alive until then, so that its memory is not handed out again meanwhile."""
+        if not self.side_overlap:      # everything in launch order on the current stream
+            yield
+            return
         dev = self.embedding_table.device
         main, side = torch.cuda.current_stream(dev), self._side_stream()
         if after is None:

@@ -3,13 +3,13 @@
 # passes whose summaries are committed under profiles/.  Usage: tools/collect_profiles.sh TAG   (e.g. r01)
 set -e -o pipefail
 TAG=${1:-r01}
-LEGS=${2:-all}     # "all", or "rest": everything but the Tmall training-step legs (bench line, kernel stats, traffic passes)
+LEGS=${2:-all}     # "all"; "tmall": the Tmall training-step legs only (traffic passes, bench line, kernel stats, step timeline); "rest": the others
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # traffic passes first: the bench lines below read the JSON they produce
-if [ "$LEGS" = all ]; then
+if [ "$LEGS" != rest ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_tmall_$c -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_tmall_$c.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_industry_$c -o p -- python $R/bench.py --workload industry --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_industry_$c.log 2>&1
@@ -19,7 +19,11 @@ cp $O/traffic.json $R/profiles/${TAG}_traffic.json
 timeout -k 10 300 python $R/bench.py --steps 50 --warmup 10 > $O/tmall_bench.json 2> $O/tmall_bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_tmall -o p -- python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/ks_tmall.log 2>&1
 cp $O/ks_tmall/p_kernel_stats.csv $O/tmall_train_step_kernel_stats.csv
+# one replayed step kernel by kernel, with the hardware queue each ran on (what runs beside the propagation)
+timeout -k 10 300 rocprofv3 --kernel-trace -d $O/kt_tmall -o step -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/kt_tmall.log 2>&1
+python $R/tools/step_timeline.py $O/kt_tmall/step_results.db 15 > $O/tmall_train_step_timeline.txt
 fi
+if [ "$LEGS" = tmall ]; then echo done; exit 0; fi
 timeout -k 10 300 python $R/bench.py --workload industry --steps 20 --warmup 5 > $O/industry_bench.json 2> $O/industry_bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_industry -o p -- python $R/bench.py --workload industry --steps 20 --warmup 5 --no-cpu-baseline > $O/ks_industry.log 2>&1
 # SQ / TA / L2 counters of the layer kernel (forward propagation only, tools/layer_bench.py)
