@@ -144,6 +144,13 @@ SIGNATURES = {
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dg_rec_head_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 4),
     "dg_rec_head_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "dg_linear_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p, C.c_void_p]),
+    "dg_linear_wgrad_workspace": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "dg_linear_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "dg_nc_logits": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dg_nc_nll_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dg_nc_nll_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 4),
     "dg_adam_prepare": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "dg_rec_head_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 10),
 }

@@ -27,6 +27,46 @@ DEFAULT_ARGS = SimpleNamespace(latdim=64, gcn_layer=3, uugcn_layer=3, dims="[64]
                                batch=8)  # DiffGraph_NC/params.py:5-68
 
 
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear on the HIP path: y = x . w^T + b and the gradients autograd forms for it."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = x.contiguous(), w.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return ops.linear_fwd(x, w, None if b is None else b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        d_w = d_b = d_x = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            d_w, d_b = ops.linear_wgrad(dy, x)
+        if ctx.needs_input_grad[0]:
+            d_x = ops.linear_fwd(dy, w.t().contiguous(), None)        # dy [n, m] . w [m, k]
+        return d_x, d_w, (d_b if ctx.has_bias else None)
+
+
+class _NLLHeadFn(torch.autograd.Function):
+    """F.nll_loss(F.log_softmax(dense(e), dim=1)[ancs], labels) (Model.py:84-89) as one differentiable op."""
+
+    @staticmethod
+    def forward(ctx, e, w, b, ancs, labels):
+        e, w, b = e.contiguous(), w.contiguous(), b.contiguous()
+        logits = ops.nc_logits(e, w, b)
+        loss, entries = ops.nc_nll_fwd(logits, ancs, labels)
+        ctx.save_for_backward(e, w, ancs, labels, entries)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        e, w, ancs, labels, entries = ctx.saved_tensors
+        d_e, d_w, d_b = ops.nc_nll_bwd(e, w, ancs, labels, entries, g.reshape(1).float().contiguous())
+        return d_e, d_w, d_b, None, None
+
+
 def _launch_distinct(tasks, launch) -> None:
     """Graphs that share a handle cannot share a launch (one hub slab per handle)."""
     seen, batch = set(), []
@@ -138,7 +178,7 @@ class HGDM(nn.Module):
         return sums, saved, norms
 
     def forward(self, he_adjs, feature_list, is_training=True):
-        embed = self.transform_layer(feature_list)
+        embed = _LinearFn.apply(feature_list, self.transform_layer.weight, self.transform_layer.bias)
         target, s1, s2 = self.propagate(he_adjs, embed)
         return s1, s2, target
 
@@ -149,10 +189,10 @@ class HGDM(nn.Module):
             self.user_denoise_model, target_embedding, source_embeddings, ancs, ts, noise, keep_mask)
         diff_loss = diff_loss.mean()
         all_embeddings = target_embedding + diff_embeddings
-        scores = F.log_softmax(self.dense(all_embeddings), dim=1)
-        batch_u = scores[ancs]
+        ancs = ancs.long().contiguous()
         batch_label = torch.argmax(label[ancs], dim=-1)
-        return F.nll_loss(batch_u, batch_label), diff_loss
+        # log_softmax(dense(.))[ancs] + nll_loss in one op: only the batch rows' scores are ever used
+        return _NLLHeadFn.apply(all_embeddings, self.dense.weight, self.dense.bias, ancs, batch_label), diff_loss
 
     def get_embeds(self, ancs, label, he_adjs, initial_feature):  # Model.py:90-99
         all_embeddings, _ = self.get_allembeds(he_adjs, initial_feature)
@@ -163,4 +203,5 @@ class HGDM(nn.Module):
         source_embeddings = s1 + s2
         diff_embeddings = self.diffusion_model.p_sample(self.user_denoise_model, source_embeddings, self.args.sampling_steps)
         all_embeddings = target_embedding + diff_embeddings
-        return all_embeddings, self.dense(all_embeddings)
+        return all_embeddings, ops.nc_logits(all_embeddings.contiguous(), self.dense.weight.detach().contiguous(),
+                                             self.dense.bias.detach().contiguous())

@@ -685,3 +685,86 @@ def rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user: int, batch_div: flo
     if full:
         return d_ui, d_out, d_rl
     return d_ui, d_out_u, d_out_i, d_rl_u, d_rl_i
+
+
+# ------------------------------------------------------------------------------ NC: the two dense layers
+def _mat(x: torch.Tensor, name: str, rows: Optional[int] = None, cols: Optional[int] = None) -> torch.Tensor:
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or not x.is_contiguous() \
+            or (rows is not None and x.shape[0] != rows) or (cols is not None and x.shape[1] != cols):
+        raise DiffGraphHipError(f"{name}: expected a contiguous float32 GPU matrix [{rows or 'n'},{cols or 'k'}], got "
+                                f"{tuple(x.shape)} {x.dtype} on {x.device}")
+    return x
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """x [n, k] . w [m, k]^T + b [m]: nn.Linear's forward (DiffGraph_NC/Model.py:47, transform_layer)."""
+    _mat(x, "x")
+    n, k = x.shape
+    _mat(w, "weight", None, k)
+    m = w.shape[0]
+    if b is not None:
+        _vec(b, "bias", torch.float32, m)
+    y = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    rc = _lib.load().dg_linear_fwd(x.data_ptr(), w.data_ptr(), _ptr(b), n, k, m, y.data_ptr(), _lib.stream_ptr(x.device))
+    _lib.check(rc, "dg_linear_fwd")
+    return y
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor):
+    """(d weight [m, k], d bias [m]) of y = x . w^T + b from dy [n, m] and x [n, k]; fixed summation order."""
+    _mat(dy, "dy")
+    n, m = dy.shape
+    _mat(x, "x", n)
+    k = x.shape[1]
+    lib = _lib.load()
+    ws_bytes = int(lib.dg_linear_wgrad_workspace(k, m))
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    d_w = torch.empty((m, k), dtype=torch.float32, device=x.device)
+    d_b = torch.empty(m, dtype=torch.float32, device=x.device)
+    rc = lib.dg_linear_wgrad(dy.data_ptr(), x.data_ptr(), n, k, m, ws.data_ptr(), ws_bytes, d_w.data_ptr(), d_b.data_ptr(),
+                             _lib.stream_ptr(x.device))
+    _lib.check(rc, "dg_linear_wgrad")
+    return d_w, d_b
+
+
+def nc_logits(e: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """self.dense(all_embeddings) (DiffGraph_NC/Model.py:84,107): e [n, 64] . w [n_cls, 64]^T + b."""
+    _table(e, "embeddings")
+    _mat(w, "dense weight", None, DG_D)
+    n_cls = w.shape[0]
+    _vec(b, "dense bias", torch.float32, n_cls)
+    out = torch.empty((e.shape[0], n_cls), dtype=torch.float32, device=e.device)
+    rc = _lib.load().dg_nc_logits(e.data_ptr(), w.data_ptr(), b.data_ptr(), e.shape[0], DG_D, n_cls, out.data_ptr(),
+                                  _lib.stream_ptr(e.device))
+    _lib.check(rc, "dg_nc_logits")
+    return out
+
+
+def nc_nll_fwd(logits: torch.Tensor, ancs: torch.Tensor, labels: torch.Tensor):
+    """F.nll_loss(F.log_softmax(logits, 1)[ancs], labels) (Model.py:84-89).  Returns (loss fp32[1], entries)."""
+    _mat(logits, "logits")
+    n, n_cls = logits.shape
+    B = ancs.numel()
+    _index_vec(ancs, "ancs", B)
+    _index_vec(labels, "labels", B)
+    entries = torch.empty((B, n_cls), dtype=torch.float32, device=logits.device)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    rc = _lib.load().dg_nc_nll_fwd(logits.data_ptr(), ancs.data_ptr(), labels.data_ptr(), B, n, n_cls, entries.data_ptr(),
+                                   loss.data_ptr(), _lib.stream_ptr(logits.device))
+    _lib.check(rc, "dg_nc_nll_fwd")
+    return loss, entries
+
+
+def nc_nll_bwd(e: torch.Tensor, w: torch.Tensor, ancs, labels, entries, g: torch.Tensor):
+    """Backward of nc_logits + nc_nll_fwd wrt (e, w, b); g: fp32[1] upstream gradient of the loss."""
+    _table(e, "embeddings")
+    n_cls = w.shape[0]
+    _vec(g, "upstream gradient", torch.float32, 1)
+    d_e = torch.zeros_like(e)
+    d_w = torch.empty_like(w)
+    d_b = torch.empty(n_cls, dtype=torch.float32, device=e.device)
+    rc = _lib.load().dg_nc_nll_bwd(e.data_ptr(), w.data_ptr(), ancs.data_ptr(), labels.data_ptr(), entries.data_ptr(),
+                                   g.data_ptr(), ancs.numel(), e.shape[0], DG_D, n_cls, d_e.data_ptr(), d_w.data_ptr(),
+                                   d_b.data_ptr(), _lib.stream_ptr(e.device))
+    _lib.check(rc, "dg_nc_nll_bwd")
+    return d_e, d_w, d_b

@@ -437,6 +437,32 @@ int dg_rec_head_bwd(const float *ui, const float *out_u, const float *out_i, con
                     double *d_row_loss_i, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * The node-classification model's two dense layers (DiffGraph_NC/Model.py).
+ * dg_linear_fwd: y[n][m] = x[n][k] . w[m][k]^T + bias[m] (bias may be NULL) -- transform_layer = nn.Linear(f_dim,
+ * latdim) on the feature matrix (:38-40,47).  dg_linear_wgrad: what autograd forms for it, d_w[m][k] = dy^T . x and
+ * d_b[m] = column sums of dy, the table rows added in 32 strips whose partial sums are added in strip order (the same
+ * bits on every run); workspace: DEVICE, dg_linear_wgrad_workspace(k, m) bytes.
+ * dg_nc_logits: logits[n][n_cls] = e[n][64] . w[n_cls][64]^T + b (self.dense, :84,107; n_cls <= 16).
+ * dg_nc_nll_fwd: loss[0] = F.nll_loss(F.log_softmax(logits, 1)[ancs], labels) (:84-89; mean over the batch, fp32);
+ * entries: DEVICE float[n_batch][n_cls], the batch rows' softmax, kept for dg_nc_nll_bwd, which writes d_w / d_b of
+ * the dense layer and ADDS the batch rows' gradients into d_e[n][64] (zeroed by the caller; entries in batch order,
+ * so a row named twice is added twice in that order); g: DEVICE float[1], the upstream gradient of the loss.  An
+ * index outside [0, n) or a label outside [0, n_cls) makes the loss NaN and is not gathered through.
+ * ---------------------------------------------------------------------------------- */
+int dg_linear_fwd(const float *x, const float *w, const float *bias, int32_t n, int32_t k, int32_t m, float *y,
+                  void *stream);
+size_t dg_linear_wgrad_workspace(int32_t k, int32_t m);
+int dg_linear_wgrad(const float *dy, const float *x, int32_t n, int32_t k, int32_t m, void *workspace,
+                    size_t workspace_bytes, float *d_w, float *d_b, void *stream);
+int dg_nc_logits(const float *e, const float *w, const float *b, int64_t n, int32_t d, int32_t n_cls, float *logits,
+                 void *stream);
+int dg_nc_nll_fwd(const float *logits, const int64_t *ancs, const int64_t *labels, int32_t n_batch, int64_t n,
+                  int32_t n_cls, float *entries, float *loss, void *stream);
+int dg_nc_nll_bwd(const float *e, const float *w, const int64_t *ancs, const int64_t *labels, const float *entries,
+                  const float *g, int32_t n_batch, int64_t n, int32_t d, int32_t n_cls, float *d_e, float *d_w,
+                  float *d_b, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Adam step of one table, the gradient given as the n_parts (<= 16) tables whose left-to-right sum
  * it is (HOST array of DEVICE pointers).  Replaces torch.optim.Adam.step() for the embedding table
  * (DiffGraph-Rec/main.py:117-119,127-128; amsgrad off) together with the final sum of the backward

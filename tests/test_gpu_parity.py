@@ -429,6 +429,62 @@ def test_rec_loss_head_index_out_of_range_gives_nan_not_a_gather():
         assert (dl[1].grad[nu - 1] == 0).all() and (dl[2].grad[ni - 1] == 0).all()
 
 
+@pytest.mark.parametrize("n,k,m", [(1, 1, 1), (63, 17, 4), (130, 334, 64), (4057, 334, 64), (1000, 64, 65)])
+def test_linear_layer_forward_and_gradients(n, k, m):
+    """The NC model's nn.Linear on the HIP path (DiffGraph_NC/Model.py:38-40,47): forward, weight / bias / input
+    gradients against the same contractions in fp64, at ragged sizes; the same bits twice."""
+    from diffgraph_amd.model_nc import _LinearFn
+    gen = torch.Generator().manual_seed(n + k)
+    x, w, b, gy = (torch.randn(*s, generator=gen) for s in ((n, k), (m, k), (m,), (n, m)))
+    xd, wd, bd = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = _LinearFn.apply(xd, wd, bd)
+    y.backward(dev(gy))
+    x6, w6, b6 = (t.double().requires_grad_(True) for t in (x, w, b))
+    y6 = x6 @ w6.t() + b6
+    y6.backward(gy.double())
+    assert_rows_close(y, y6, what="linear forward")
+    assert_close_to_max(wd.grad, w6.grad, 1e-5, "linear d weight")
+    assert_close_to_max(bd.grad, b6.grad, 1e-5, "linear d bias")
+    assert_rows_close(xd.grad, x6.grad, what="linear d input")
+    y2 = _LinearFn.apply(xd, wd, bd)
+    g2 = ops.linear_wgrad(dev(gy), dev(x))
+    assert torch.equal(y, y2) and torch.equal(g2[0], wd.grad) and torch.equal(g2[1], bd.grad)
+    no_bias = _LinearFn.apply(dev(x), dev(w), None)
+    assert_rows_close(no_bias, x.double() @ w.double().t(), what="linear forward, no bias")
+
+
+def test_nc_classification_head_matches_torch():
+    """dense + log_softmax + batch rows + nll_loss (DiffGraph_NC/Model.py:84-89) as one op against torch's, with a
+    batch that names rows twice; the logits of get_allembeds (:107); an index out of range gives NaN, no gather."""
+    import torch.nn.functional as F
+    from diffgraph_amd.model_nc import _NLLHeadFn
+    gen = torch.Generator().manual_seed(4)
+    n, n_cls, B = 500, 4, 37
+    e, w, b = torch.randn(n, 64, generator=gen), torch.randn(n_cls, 64, generator=gen) * 0.3, torch.randn(n_cls, generator=gen)
+    ancs = torch.randint(0, n, (B,), generator=gen)
+    ancs[5] = ancs[2]
+    ancs[30] = ancs[2]
+    labels = torch.randint(0, n_cls, (B,), generator=gen)
+    ed, wd, bd = (dev(t).requires_grad_(True) for t in (e, w, b))
+    loss = _NLLHeadFn.apply(ed, wd, bd, dev(ancs), dev(labels))
+    (loss * 1.7).backward()
+    e6, w6, b6 = (t.double().requires_grad_(True) for t in (e, w, b))
+    want = F.nll_loss(F.log_softmax(e6 @ w6.t() + b6, dim=1)[ancs], labels)
+    (want * 1.7).backward()
+    assert float(loss.detach()) == pytest.approx(float(want.detach()), rel=1e-5)
+    assert_rows_close(ed.grad, e6.grad, what="nc head d embeddings")
+    assert_close_to_max(wd.grad, w6.grad, 1e-5, "nc head d weight")
+    assert_close_to_max(bd.grad, b6.grad, 1e-5, "nc head d bias")
+    assert_rows_close(ops.nc_logits(dev(e), dev(w), dev(b)), (e6 @ w6.t() + b6).detach(), what="nc logits")
+    bad = ancs.clone()
+    bad[3] = n
+    ed2 = dev(e).requires_grad_(True)
+    loss_bad = _NLLHeadFn.apply(ed2, dev(w), dev(b), dev(bad), dev(labels))
+    assert torch.isnan(loss_bad)
+    loss_bad.backward()
+    torch.cuda.synchronize()
+
+
 def test_adam_matches_torch_adam_over_steps():
     """diffgraph_amd.optim.Adam (table kernel fed with the backward pass's gradient parts + torch's Adam for the
     denoisers) against torch.optim.Adam on an identical model (DiffGraph-Rec/main.py:117-119), five steps."""
