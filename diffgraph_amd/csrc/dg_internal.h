@@ -97,7 +97,7 @@ struct dg_csr {
   int32_t *witems = nullptr;
   int32_t n_windows = 0, n_parts = 0;
   // Dense graphs (at least DG_DENSE_MIN_DENSITY of all node pairs are edges, no repeated edge): the adjacency as
-  // a bitmap, contracted with the table on the fp32 matrix cores by dense_rows_kernel instead of gathered row by
+  // a bitmap, contracted with the table on the matrix cores by dense_rows_kernel instead of gathered row by
   // row.  dense_bits[(tile * dense_chunks + c) * 32 + i] holds columns [64 c, 64 c + 64) of row 32 tile + i
   // (bit b = column 64 c + b).  The columns are cut into dense_splits ranges of dense_cps chunks; a wavefront sums
   // one (32-row tile, range) into slab rows row * dense_splits + range, and hub_reduce_kernel adds a row's ranges
@@ -116,7 +116,9 @@ struct dg_graph {
   dg_csr fwd;                 // rows = destinations, columns = sources
   dg_csr bwd;                 // rows = sources, columns = destinations (aliases fwd when symmetric)
   float *slab = nullptr;      // [max(fwd.n_seg,bwd.n_seg)][64] partial sums of hub-row segments
-  float *dense_x = nullptr;   // [n][64], dense graphs only: the table times the gathered node's norm, when the caller's is not
+  // dense graphs only: the layer's input table as three bf16 planes [3][64 features][64 dense_chunks rows] that
+  // add up to the fp32 values (times the gathered node's norm when the caller's table is not scaled yet)
+  float *dense_x = nullptr;
   int device = 0;
 };
 

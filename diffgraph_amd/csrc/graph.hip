@@ -492,7 +492,7 @@ extern "C" int dg_graph_create_ex(int32_t n, int64_t nnz, const int32_t *src, co
     e = hipMalloc((void **)&g->slab, std::max<size_t>(segs, 1) * DG_D * sizeof(float));
   }
   if (e == hipSuccess && (g->fwd.dense_splits > 0 || g->bwd.dense_splits > 0))
-    e = hipMalloc((void **)&g->dense_x, (size_t)n * DG_D * sizeof(float));
+    e = hipMalloc((void **)&g->dense_x, (size_t)3 * DG_D * std::max(g->fwd.dense_chunks, g->bwd.dense_chunks) * 64 * sizeof(uint16_t));
   if (e != hipSuccess) {
     dg_graph_destroy(g);
     return dg_fail((int)e, "dg_graph_create: device allocation/copy failed: %s", hipGetErrorString(e));

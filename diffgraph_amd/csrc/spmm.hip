@@ -540,20 +540,28 @@ __global__ __launch_bounds__(1024) void window_rows_kernel(const dg_task_batch b
 }
 
 constexpr int kDenseWaves = DG_DENSE_TILES_PER_BLOCK;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kDensePitch = 144;                        // bytes of one staged column: 64 bf16 + 16 B (conflict-free 16-B reads)
+constexpr int kDensePlane = 64 * kDensePitch;           // one plane of one 64-row stage
+constexpr int kDenseStage = 3 * kDensePlane;
 
-// Dense graphs (dg_csr::dense_bits): Y = A . X on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 with the
-// adjacency bitmap expanded to 0.0 / 1.0 in registers.  A workgroup owns kDenseWaves consecutive 32-row tiles of A
-// (one per wavefront) and one range of its columns (= table rows); the table rows of the range pass through LDS 64
-// at a time (two buffers: the next 64 are on their way while the current ones are multiplied), so every wavefront
-// of the workgroup reads them from there.  Lane (i = lane & 31, kk = lane >> 5) holds the 64-bit word of row i of
-// its tile for the current 64 columns and, per step s, supplies bit 2s + kk as the A operand and
-// table[64 c + 2s + kk][i], [32 + i] as the B operands of the two 32-column halves.  The instruction is a k-ordered
-// fmaf chain and 1.0 * x is exact, so the result is the plain fp32 sum of the neighbour rows in ascending id order
-// -- the order the reference's update_all adds them in.  Table rows come through a buffer descriptor (ids past n
-// read zeros).  The tile's 32 x 64 partial sums go to slab rows row * dense_splits + range; hub_reduce_kernel adds a
-// row's ranges in order and applies the epilogue.
+// Dense graphs (dg_csr::dense_bits): Y = A . X on the matrix cores with the adjacency bitmap expanded to 0.0 / 1.0
+// in registers.  The table arrives as three bf16 planes whose sum is the fp32 value exactly (dense_split_kernel:
+// hi = the top 8 significand bits, mid = the next 8, lo = the last 8), stored transposed, plane[p][feature][row], so
+// that the 8 consecutive table rows a lane supplies to v_mfma_f32_32x32x16_bf16 are 16 contiguous bytes.  Every
+// product 1.0 * plane value is exact and the accumulator is fp32: the result is the fp32 sum of the neighbour rows,
+// its rounding errors those of fp32 additions (in the instruction's order of adding, not ascending neighbour order),
+// at a sixteenth of the cycles the fp32 matrix instruction takes even with three planes to add.
+// A workgroup owns kDenseWaves consecutive 32-row tiles of A (one per wavefront) and one range of its columns
+// (= table rows); the range passes through LDS 64 table rows at a time (two buffers: the next 64 are on their way
+// while the current ones are multiplied), so every wavefront of the workgroup reads them from there.  Lane
+// (i = lane & 31, kk = lane >> 5) holds the 64-bit word of row i of its tile for the current 64 columns; in step t
+// byte 2 t + kk of it becomes the A operand (columns 16 t + 8 kk ..+8) and plane[p][i or 32 + i][16 t + 8 kk ..+8]
+// the B operands of the two 32-feature halves.  The tile's 32 x 64 partial sums go to slab rows
+// row * dense_splits + range; hub_reduce_kernel adds a row's ranges in order and applies the epilogue.
 __global__ __launch_bounds__(64 * kDenseWaves) void dense_rows_kernel(const dg_task_batch batch) {
-  __shared__ f32x4 xs[2][64][16];
+  __shared__ __attribute__((aligned(16))) unsigned char xs[2 * kDenseStage];
   int ti = 0;
   for (int k = 0; k < batch.n_tasks; ++k)
     if (batch.t[k].dense_splits > 0 && (int)blockIdx.x >= batch.t[k].dense_blk_begin) ti = k;
@@ -562,22 +570,25 @@ __global__ __launch_bounds__(64 * kDenseWaves) void dense_rows_kernel(const dg_t
   const int lb = blockIdx.x - T.dense_blk_begin;
   const int S = T.dense_splits, group = lb / S, split = lb - group * S;
   const int tile = group * kDenseWaves + wave;   // (the bitmap is allocated for whole tile groups: a missing tile reads zeros)
-  const float *tab = (T.flags & DG_IN_PRESCALED) ? T.x : T.dense_x;
-  const __amdgpu_buffer_rsrc_t xr = table_rsrc(tab, T.n);
+  const unsigned row_bytes = (unsigned)T.dense_chunks * 128u;      // one feature of one plane: 64 bf16 per chunk
+  const unsigned char *planes = reinterpret_cast<const unsigned char *>(T.dense_x);
   const int c0 = split * T.dense_cps, c1 = min(c0 + T.dense_cps, T.dense_chunks);
   const uint64_t *bits = T.dense_bits + ((size_t)tile * T.dense_chunks) * 32 + i;
-  constexpr int kPer = 1024 / (64 * kDenseWaves);   // float4 per thread of one 64-row stage
-  f32x4 pre[kPer];
+  constexpr int kPer = 3 * 512 / (64 * kDenseWaves);   // 16-B pieces per thread of one stage (3 planes x 64 features x 8)
+  u32x4 pre[kPer];
   auto fetch = [&](int c) {
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
-      const unsigned idx = threadIdx.x + 64 * kDenseWaves * j;   // row idx >> 4 of the stage, float4 idx & 15
-      pre[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(64 * c) * (unsigned)(DG_D * 4) + idx * 16u, 0, 0));
+      const unsigned idx = threadIdx.x + 64 * kDenseWaves * j, p = idx >> 9, f = (idx >> 3) & 63, q = idx & 7;
+      pre[j] = *reinterpret_cast<const u32x4 *>(planes + (size_t)(p * 64 + f) * row_bytes + (unsigned)c * 128u + q * 16u);
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) (&xs[buf][0][0])[threadIdx.x + 64 * kDenseWaves * j] = pre[j];
+    for (int j = 0; j < kPer; ++j) {
+      const unsigned idx = threadIdx.x + 64 * kDenseWaves * j, p = idx >> 9, f = (idx >> 3) & 63, q = idx & 7;
+      *reinterpret_cast<u32x4 *>(xs + buf * kDenseStage + p * kDensePlane + f * kDensePitch + q * 16) = pre[j];
+    }
   };
   f32x16 acc0 = {0.f}, acc1 = {0.f};
   fetch(c0);
@@ -591,21 +602,21 @@ __global__ __launch_bounds__(64 * kDenseWaves) void dense_rows_kernel(const dg_t
       fetch(c + 1);
       wn = bits[(size_t)(c + 1) * 32];
     }
-    const uint32_t lo = (uint32_t)(wb >> kk), hi = (uint32_t)(wb >> (32 + kk));
-    const float *xb = reinterpret_cast<const float *>(&xs[cur][0][0]) + kk * DG_D + i;
-    // all of the chunk's B operands are asked for before the first product: one exposed LDS round trip per chunk
-    float b0[32], b1[32];
+    const unsigned char *xb = xs + cur * kDenseStage + i * kDensePitch + kk * 16;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      b0[s] = xb[2 * s * DG_D];
-      b1[s] = xb[2 * s * DG_D + 32];
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keeps the reads above the products (the scheduler would sink each to its use)
+    for (int t = 0; t < 4; ++t) {
+      const unsigned ab = (unsigned)(wb >> (16 * t + 8 * kk)) & 0xffu;
+      u32x4 av;   // two bf16 per dword: 1.0 = 0x3F80
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const float a = (float)(((s < 16 ? lo : hi) >> (2 * (s & 15))) & 1u);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], acc1, 0, 0, 0);
+      for (int d = 0; d < 4; ++d) av[d] = ((ab >> (2 * d)) & 1u) * 0x3F80u + ((ab >> (2 * d + 1)) & 1u) * 0x3F800000u;
+      const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(xb + p * kDensePlane + t * 32);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(xb + p * kDensePlane + 32 * kDensePitch + t * 32);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
+      }
     }
     if (c + 1 < c1) stash(cur ^ 1);
     __syncthreads();
@@ -624,14 +635,47 @@ __global__ __launch_bounds__(64 * kDenseWaves) void dense_rows_kernel(const dg_t
   }
 }
 
-// table * norm of the gathered node, for dense graphs whose input is not scaled yet (the first layer)
-__global__ __launch_bounds__(256) void dense_prescale_kernel(const dg_task_batch batch) {
+// The table of a dense graph as dense_rows_kernel reads it: times the norm of the gathered node when the caller's is
+// not scaled yet (the first layer), cut into three bf16 planes that add up to the fp32 value exactly -- truncation
+// keeps every remainder representable: hi = the value's upper 16 bits, mid = those of value - hi, lo = the rest,
+// at most 8 significant bits -- and transposed to plane[p][feature][row], rows padded with zeros to whole 64-row
+// chunks.  One workgroup per chunk of 64 table rows.
+__global__ __launch_bounds__(256) void dense_split_kernel(const dg_task_batch batch) {
+  __shared__ unsigned short tr[3][64][72];   // [plane][feature][row of the chunk]
   const dg_task_dev &T = batch.t[blockIdx.y];
-  if (T.dense_splits <= 0 || (T.flags & DG_IN_PRESCALED)) return;
-  const int l = threadIdx.x & 15;
-  for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < T.n; row += gridDim.x * 16) {
-    const size_t o = (size_t)row * (DG_D / 4) + l;
-    reinterpret_cast<f32x4 *>(T.dense_x)[o] = reinterpret_cast<const f32x4 *>(T.x)[o] * T.dinv_gather[row];
+  if (T.dense_splits <= 0 || (int)blockIdx.x >= T.dense_chunks) return;   // (the whole workgroup)
+  const int c = blockIdx.x, r = threadIdx.x >> 2, f0 = (threadIdx.x & 3) * 16, row = 64 * c + r;
+  const bool scale = !(T.flags & DG_IN_PRESCALED);
+  float s = 0.f;
+  if (row < T.n) s = scale ? T.dinv_gather[row] : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < T.n) {
+      v = reinterpret_cast<const f32x4 *>(T.x)[(size_t)row * (DG_D / 4) + (f0 >> 2) + j];
+      if (scale) v *= s;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e];
+      const unsigned hb = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+      const float r1 = x - __builtin_bit_cast(float, hb);
+      const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+      const float r2 = r1 - __builtin_bit_cast(float, mb);
+      const int f = f0 + 4 * j + e;
+      tr[0][f][r] = (unsigned short)(hb >> 16);
+      tr[1][f][r] = (unsigned short)(mb >> 16);
+      tr[2][f][r] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    }
+  }
+  __syncthreads();
+  unsigned char *planes = reinterpret_cast<unsigned char *>(T.dense_x);
+  const unsigned row_bytes = (unsigned)T.dense_chunks * 128u;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const unsigned idx = threadIdx.x + 256 * j, p = idx >> 9, f = (idx >> 3) & 63, q = idx & 7;
+    *reinterpret_cast<u32x4 *>(planes + (size_t)(p * 64 + f) * row_bytes + (unsigned)c * 128u + q * 16u) =
+        *reinterpret_cast<const u32x4 *>(&tr[p][f][8 * q]);
   }
 }
 
@@ -795,8 +839,7 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
       }
     }
   }
-  int32_t dense_blocks = 0;
-  bool dense_prescale = false;
+  int32_t dense_blocks = 0, dense_chunks_max = 0;
   for (int k = 0; k < n_tasks; ++k) {
     dg_task_dev &t = batch.t[k];
     t.dense_blk_begin = dense_blocks;
@@ -804,12 +847,12 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
       for (int j = 0; j < k; ++j)
         if (graphs[j] == graphs[k]) return dg_fail(DG_ERR_ARG, "layer tasks %d and %d share a dense graph (one slab per graph)", j, k);
       dense_blocks += ((t.dense_tiles + kDenseWaves - 1) / kDenseWaves) * t.dense_splits;
-      dense_prescale = dense_prescale || !(t.flags & DG_IN_PRESCALED);
+      dense_chunks_max = max(dense_chunks_max, t.dense_chunks);
     }
   }
   for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
   if (dense_blocks > 0) {
-    if (dense_prescale) hipLaunchKernelGGL(dense_prescale_kernel, dim3(256, n_tasks), dim3(256), 0, stream, batch);
+    hipLaunchKernelGGL(dense_split_kernel, dim3(dense_chunks_max, n_tasks), dim3(256), 0, stream, batch);
     hipLaunchKernelGGL(dense_rows_kernel, dim3(dense_blocks), dim3(64 * kDenseWaves), 0, stream, batch);
   }
   if (lds_blocks > 0 && full_rows) {
