@@ -30,7 +30,9 @@
 // dense_rows_kernel: 32-row tiles (one per wavefront) that share the table rows a workgroup stages, and the number of
 // workgroups a graph is cut into (about one per CU, so that one dense graph alone fills the chip)
 #define DG_DENSE_TILES_PER_BLOCK 4
+#ifndef DG_DENSE_BLOCKS_PER_GRAPH
 #define DG_DENSE_BLOCKS_PER_GRAPH 256
+#endif
 #define DG_DENSE_MAX_NODES 32768  // bitmap of n^2 / 8 bytes: 128 MiB at the limit
 
 // Records a printf-style message retrievable through dg_last_error(); returns `code`.
