@@ -16,11 +16,11 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 
-def synth_interactions(n_user: int, n_item: int, n_links: int, seed: int, zipf_alpha: float = 1.0
-                       ) -> Tuple[np.ndarray, np.ndarray]:
-    """`n_links` DISTINCT (user, item) pairs: user uniform, item ~ Zipf(alpha) over a
-    seeded permutation of the items; duplicate pairs are re-drawn.  Returned sorted by
-    (user, item) as int32 arrays."""
+def synth_interactions(n_user: int, n_item: int, n_links: int, seed: int, zipf_alpha: float = 1.0,
+                       user_zipf_alpha: float = 0.0) -> Tuple[np.ndarray, np.ndarray]:
+    """`n_links` DISTINCT (user, item) pairs: user uniform (or ~ Zipf(user_zipf_alpha) over a seeded permutation
+    of the users when that is > 0), item ~ Zipf(alpha) over a seeded permutation of the items; duplicate pairs
+    are re-drawn.  Returned sorted by (user, item) as int32 arrays."""
     if n_links > n_user * n_item:
         raise ValueError("more links requested than user x item cells")
     rng = np.random.default_rng(seed)
@@ -28,11 +28,20 @@ def synth_interactions(n_user: int, n_item: int, n_links: int, seed: int, zipf_a
     w = 1.0 / np.power(np.arange(1, n_item + 1, dtype=np.float64), zipf_alpha)
     cdf = np.cumsum(w)
     cdf /= cdf[-1]
+    if user_zipf_alpha > 0:      # (drawn after the item permutation: the uniform-user graphs stay what they were)
+        uperm = rng.permutation(n_user)
+        uw = 1.0 / np.power(np.arange(1, n_user + 1, dtype=np.float64), user_zipf_alpha)
+        ucdf = np.cumsum(uw)
+        ucdf /= ucdf[-1]
     keys = np.empty(0, dtype=np.int64)
     while keys.size < n_links:
         need = n_links - keys.size
         m = int(need * 1.15) + 1024
-        u = rng.integers(0, n_user, size=m, dtype=np.int64)
+        if user_zipf_alpha > 0:
+            ur = np.searchsorted(ucdf, rng.random(m), side="right")
+            u = uperm[np.minimum(ur, n_user - 1)].astype(np.int64)
+        else:
+            u = rng.integers(0, n_user, size=m, dtype=np.int64)
         r = np.searchsorted(cdf, rng.random(m), side="right")
         np.minimum(r, n_item - 1, out=r)
         i = perm[r].astype(np.int64)
@@ -71,6 +80,9 @@ _REC_SHAPES: Dict[str, tuple] = {
                       "synthetic graph with Retail Rocket's shape and per-behaviour link counts"),
     "tmall": (31882, 31232, 167862, [("pv", 1093807, 4), ("fav", 49482, 31), ("cart", 140068, 32)],
               "synthetic graph with Tmall's shape; buy/cart/fav link counts as shipped, pv synthesised"),
+    "tmall_skewed": (31882, 31232, 167862, [("pv", 1093807, 4), ("fav", 49482, 31), ("cart", 140068, 32)],
+                     "Tmall's shape and link counts with heavy-tailed users as well (users ~ Zipf(0.8), items ~ Zipf(1)): "
+                     "hub rows on both sides"),
     "ijcai": (22438, 35573, 199654, [("click", 440265, 5), ("fav", 158119, 41), ("cart", 1330, 42)],
               "synthetic graph with the shipped IJCAI shape (22 438 x 35 573); click synthesised"),
     "ijcai_readme": (17435, 35920, 198243, [("click", 439652, 6), ("fav", 159874, 43), ("cart", 1599, 44)],
@@ -79,15 +91,18 @@ _REC_SHAPES: Dict[str, tuple] = {
     "industry": (1000000, 361, 11945223, [("rel1", 7167133, 11), ("rel2", 4778089, 12)],
                  "synthetic Industry-shaped graph (1M x 361, 23 890 445 links over 3 relations)"),
 }
-_TARGET_SEED = {"tiny": 100, "retail_rocket": 20, "tmall": 30, "ijcai": 40, "ijcai_readme": 45, "industry": 10}
+_TARGET_SEED = {"tiny": 100, "retail_rocket": 20, "tmall": 30, "tmall_skewed": 30, "ijcai": 40, "ijcai_readme": 45,
+                "industry": 10}
+_USER_ALPHA = {"tmall_skewed": 0.8}     # every other workload draws its users uniformly
 
 
 def rec_workload(name: str) -> RecWorkload:
     n_user, n_item, n_target, aux, note = _REC_SHAPES[name]
-    target = synth_interactions(n_user, n_item, n_target, _TARGET_SEED[name])
+    ua = _USER_ALPHA.get(name, 0.0)
+    target = synth_interactions(n_user, n_item, n_target, _TARGET_SEED[name], user_zipf_alpha=ua)
     if name == "tiny":
         target = _tiny_edge_cases(*target, n_user, n_item)
-    behaviours = [synth_interactions(n_user, n_item, m, s) for (_, m, s) in aux]
+    behaviours = [synth_interactions(n_user, n_item, m, s, user_zipf_alpha=ua) for (_, m, s) in aux]
     if name == "tiny":
         behaviours = [_tiny_edge_cases(u, i, n_user, n_item) for (u, i) in behaviours]
     return RecWorkload(name, n_user, n_item, target, behaviours, [a[0] for a in aux], note)

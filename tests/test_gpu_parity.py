@@ -1002,6 +1002,28 @@ def test_tmall_size_forward_and_cal_loss_against_oracle():
             assert_close_to_max(gv, getattr(w, nm).grad, GRAD_TOL, "tmall grad " + pre + nm)
 
 
+def test_tmall_shape_with_heavy_tailed_users_against_oracle():
+    """The Tmall-sized graphs with hub rows on BOTH sides (users ~ Zipf(0.8): 2 600 user rows are summed in pieces,
+    the largest over 10 000 neighbours; the benchmarked shapes draw users uniformly): every row of the forward
+    against the oracle in fp64, and the schedule really has cut rows among the users."""
+    wl = dgdata.rec_workload("tmall_skewed")
+    nu, ni = wl.n_user, wl.n_item
+    graphs = [graph_of(*ui, nu, ni) for ui in [wl.target] + wl.behaviours]
+    pv = graphs[1]
+    sched = pv.schedule()
+    deg_u = np.bincount(wl.behaviours[0][0], minlength=nu)
+    assert sched["n_hub"] >= int((deg_u > 64).sum()) > 2000 and deg_u.max() > 5000
+    from types import SimpleNamespace
+    m = dg.rec.HGDM(SimpleNamespace(userNum=nu, itemNum=ni, target_adj=graphs[0], behavior_mats=graphs[1:])).eval()
+    ue, ie = T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))
+    m.set_embeddings(dev(ue), dev(ie))
+    with torch.no_grad():
+        fwd = m.forward()
+    want = O.rec_forward(edges_t(*wl.target, nu), [edges_t(*b, nu) for b in wl.behaviours], ue.double(), ie.double(), 2)
+    for got, w, nm in zip(fwd, want, ("tu", "ti", "hu", "hi")):
+        assert_rows_close(got, w, what="tmall, heavy-tailed users: forward " + nm)
+
+
 def test_industry_size_forward_against_oracle():
     """The Industry-shaped graph at full size (1M x 361, 47.8M directed edges): the whole two-layer forward, every
     row, against the oracle evaluated in fp64.  (Item rows here sum 10^4..10^6 neighbours: the fp32 oracle adds

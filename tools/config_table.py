@@ -77,7 +77,7 @@ def measure(name):
 
 def main():
     out = sys.argv[1]
-    names = sys.argv[2:] or ["retail_rocket", "tmall", "ijcai", "ijcai_readme", "dblp", "industry"]
+    names = sys.argv[2:] or ["retail_rocket", "tmall", "tmall_skewed", "ijcai", "ijcai_readme", "dblp", "industry"]
     res = []
     for nm in names:
         r = measure(nm)
