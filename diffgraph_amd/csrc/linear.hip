@@ -16,7 +16,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kTile = 64;   // output tile 64 x 64 per 256-thread workgroup, 4 x 4 per thread
+constexpr int kTile = 64;   // columns of an output tile; its rows: 64 (4 x 4 outputs per thread) or 16 (1 x 4)
 constexpr int kStep = 16;   // reduction steps staged per round
 
 // C[i][j] (+)= sum_r A(r, i) * B(r, j) over r in [r0, r1): A(r, i) = a[i * lda_i + r * lda_r], B likewise.
@@ -27,59 +27,93 @@ struct tile_args {
   int ni, nj;
 };
 
-__device__ __forceinline__ void tile_product(const tile_args &t, int i0, int j0, int64_t r0, int64_t r1, float (&acc)[4][4]) {
-  __shared__ float as[kStep][kTile + 4], bs[kStep][kTile + 4];
+// TI = rows of the tile (64 or 16); thread (ty = tid >> 4, tx = tid & 15) owns rows (TI / 16) ty .., columns 4 tx ..
+// Consecutive threads read consecutive addresses of an operand whichever of its two strides is 1; the next round's
+// elements are requested before the current round is multiplied.  colsum (threads < TI, when asked for): the sum
+// over r of A(r, i0 + tid), rounds and rows in order.
+template <int TI, bool COLSUM>
+__device__ __forceinline__ void tile_product(const tile_args &t, int i0, int j0, int64_t r0, int64_t r1, float (&acc)[TI / 16][4],
+                                             float &colsum) {
+  constexpr int U = TI / 16;
+  __shared__ float as[kStep][TI + 4], bs[kStep][kTile + 4];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0.f;
-  for (int64_t r = r0; r < r1; r += kStep) {
-    // 64 x 16 elements of each operand, four per thread
+  colsum = 0.f;
+  const bool a_along_r = t.lda_r == 1, b_along_r = t.ldb_r == 1;
+  int a_i[U], a_r[U], b_j[4], b_r[4];
+#pragma unroll
+  for (int e = 0; e < U; ++e) {
+    const int idx = tid + 256 * e;
+    a_i[e] = a_along_r ? idx >> 4 : idx % TI;
+    a_r[e] = a_along_r ? idx & 15 : idx / TI;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + 256 * e;
+    b_j[e] = b_along_r ? idx >> 4 : idx & 63;
+    b_r[e] = b_along_r ? idx & 15 : idx >> 6;
+  }
+  float av[U], bv[4];
+  auto fetch = [&](int64_t r) {
+#pragma unroll
+    for (int e = 0; e < U; ++e) {
+      const int64_t row = r + a_r[e];
+      av[e] = 0.f;
+      if (row < r1 && i0 + a_i[e] < t.ni) av[e] = t.a[(int64_t)(i0 + a_i[e]) * t.lda_i + row * t.lda_r];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int idx = tid + 256 * e, ii = idx >> 4, rr = idx & 15;
-      const int64_t row = r + rr;
-      float av = 0.f, bv = 0.f;
-      if (row < r1) {
-        if (i0 + ii < t.ni) av = t.a[(int64_t)(i0 + ii) * t.lda_i + row * t.lda_r];
-        if (j0 + ii < t.nj) bv = t.b[(int64_t)(j0 + ii) * t.ldb_j + row * t.ldb_r];
-      }
-      as[rr][ii] = av;
-      bs[rr][ii] = bv;
+      const int64_t row = r + b_r[e];
+      bv[e] = 0.f;
+      if (row < r1 && j0 + b_j[e] < t.nj) bv[e] = t.b[(int64_t)(j0 + b_j[e]) * t.ldb_j + row * t.ldb_r];
     }
+  };
+  fetch(r0);
+  for (int64_t r = r0; r < r1; r += kStep) {
+#pragma unroll
+    for (int e = 0; e < U; ++e) as[a_r[e]][a_i[e]] = av[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bs[b_r[e]][b_j[e]] = bv[e];
     __syncthreads();
+    if (r + kStep < r1) fetch(r + kStep);
 #pragma unroll
     for (int rr = 0; rr < kStep; ++rr) {
-      const f32x4 av = *reinterpret_cast<const f32x4 *>(&as[rr][4 * ty]);
-      const f32x4 bv = *reinterpret_cast<const f32x4 *>(&bs[rr][4 * tx]);
+      float ar[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < U; ++u) ar[u] = as[rr][U * ty + u];
+      const f32x4 br = *reinterpret_cast<const f32x4 *>(&bs[rr][4 * tx]);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(av[u], bv[v], acc[u][v]);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(ar[u], br[v], acc[u][v]);
+    }
+    if (COLSUM && tid < TI) {
+#pragma unroll
+      for (int rr = 0; rr < kStep; ++rr) colsum += as[rr][tid];
     }
     __syncthreads();
   }
 }
 
-// y[n][m] = x[n][k] . w[m][k]^T + bias[m]
+// y[n][m] = x[n][k] . w[m][k]^T + bias[m]; 16-row tiles: a few thousand rows then make a few hundred workgroups
+constexpr int kFwdRows = 16;
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                          const float *__restrict__ bias, int n, int k, int m,
                                                          float *__restrict__ y) {
   tile_args t = {x, w, (int64_t)k, 1, (int64_t)k, 1, n, m};
-  const int i0 = blockIdx.x * kTile, j0 = blockIdx.y * kTile;
-  float acc[4][4];
-  tile_product(t, i0, j0, 0, k, acc);
+  const int i0 = blockIdx.x * kFwdRows, j0 = blockIdx.y * kTile;
+  float acc[1][4], unused;
+  tile_product<kFwdRows, false>(t, i0, j0, 0, k, acc, unused);
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int i = i0 + ty;
+  if (i >= n) return;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int i = i0 + 4 * ty + u;
-    if (i >= n) continue;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int j = j0 + 4 * tx + v;
-      if (j < m) y[(int64_t)i * m + j] = acc[u][v] + (bias ? bias[j] : 0.f);
-    }
+  for (int v = 0; v < 4; ++v) {
+    const int j = j0 + 4 * tx + v;
+    if (j < m) y[(int64_t)i * m + j] = acc[0][v] + (bias ? bias[j] : 0.f);
   }
 }
 
@@ -90,8 +124,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_partial_kernel(const float *
   tile_args t = {dy, x, 1, (int64_t)m, 1, (int64_t)k, m, k};
   const int i0 = blockIdx.x * kTile, j0 = blockIdx.y * kTile, s = blockIdx.z;
   const int64_t r0 = (int64_t)s * rows_per_strip, r1 = min(r0 + rows_per_strip, (int64_t)n);
-  float acc[4][4];
-  tile_product(t, i0, j0, r0, r1, acc);
+  float acc[4][4], colsum;
+  tile_product<kTile, true>(t, i0, j0, r0, r1, acc, colsum);
   float *P = partial + (size_t)s * ((size_t)m * k + m);
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
 #pragma unroll
@@ -106,11 +140,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_partial_kernel(const float *
   }
   if (blockIdx.y == 0 && (int)threadIdx.x < kTile) {   // the bias gradient of this strip: rows in order
     const int o = i0 + threadIdx.x;
-    if (o < m) {
-      float sum = 0.f;
-      for (int64_t r = r0; r < r1; ++r) sum += dy[r * m + o];
-      P[(size_t)m * k + o] = sum;
-    }
+    if (o < m) P[(size_t)m * k + o] = colsum;
   }
 }
 
@@ -214,7 +244,7 @@ extern "C" int dg_linear_fwd(const float *x, const float *w, const float *bias, 
   if (!x || !w || !y) return dg_fail(DG_ERR_ARG, "dg_linear_fwd: NULL argument");
   if (n < 0 || k <= 0 || m <= 0) return dg_fail(DG_ERR_ARG, "dg_linear_fwd: bad sizes");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3((n + kTile - 1) / kTile, (m + kTile - 1) / kTile), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((n + kFwdRows - 1) / kFwdRows, (m + kTile - 1) / kTile), dim3(256), 0, (hipStream_t)stream,
                      x, w, bias, n, k, m, y);
   DG_HIP(hipGetLastError());
   return 0;
