@@ -401,7 +401,7 @@ def test_rec_loss_head_matches_torch_autograd(n_batch, nu, ni):
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5 if n_batch <= 2048 else 3e-5)
     (got * dev(wts)).sum().backward()
     for nm, g, w in zip(("ui", "out_u", "out_i", "row_loss_u", "row_loss_i"), dl, leaves):
-        assert_close_to_max(g.grad, w.grad, 2e-5, "head grad " + nm)
+        assert_close_to_max(g.grad, w.grad, 1e-5, "head grad " + nm)
     # the same bits on every run (fixed summation order over repeated rows)
     dl2 = [dev(t).requires_grad_(True) for t in (ui, out_u, out_i, rl_u, rl_i)]
     (_RecHeadFn.apply(*dl2, dev(ancs), dev(poss), dev(negs), nu, batch_div, reg) * dev(wts)).sum().backward()
@@ -575,15 +575,15 @@ def test_nc_dblp_golden(tag):
     for nm, o in (("target", sums[0]), ("s1", sums[1]), ("s2", sums[2])):
         assert_rows_close(o[rows], fx[f"{tag}_{nm}_rows"], what=f"{tag} {nm}")
     s1, s2, tgt = model.forward(adjs, dev(features))
-    assert_rows_close(tgt[rows], fx[f"{tag}_target_rows"], rtol=2e-5, what=f"{tag} forward target")
+    assert_rows_close(tgt[rows], fx[f"{tag}_target_rows"], rtol=1e-5, what=f"{tag} forward target")
     emb, scores = model.get_allembeds(adjs, dev(features))
-    assert_rows_close(emb[rows], fx[f"{tag}_allembeds_rows"], rtol=2e-5, what=f"{tag} allembeds")
+    assert_rows_close(emb[rows], fx[f"{tag}_allembeds_rows"], rtol=1e-5, what=f"{tag} allembeds")
     assert_rows_close(scores[rows], fx[f"{tag}_scores_rows"], rtol=1e-5, what=f"{tag} scores")
     if tag == "coded":
         onehot = torch.zeros(NA, 4)
         onehot[torch.arange(NA), T(load("dblp_graph.npz")["labels"])] = 1.0
         nll, diff = model.cal_loss(dev(fx["cl_ancs"]), dev(onehot), adjs, dev(features), dev(fx["cl_ts"]), dev(fx["cl_noise"]))
-        np.testing.assert_allclose([float(nll.detach()), float(diff.detach())], fx["cl_losses"], rtol=2e-5)
+        np.testing.assert_allclose([float(nll.detach()), float(diff.detach())], fx["cl_losses"], rtol=1e-5)
 
 
 # ------------------------------------------------------------------------------ full size
@@ -604,7 +604,7 @@ def test_tmall_size_properties():
     z = dev(torch.randn(n, 64, generator=gen))
     lhs = ops.spmm_norm_act(g, 2.0 * xd - 0.5 * z, 1.0)
     rhs = 2.0 * y - 0.5 * ops.spmm_norm_act(g, z, 1.0)
-    assert_rows_close(lhs, rhs, rtol=2e-5, what="linearity")
+    assert_rows_close(lhs, rhs, rtol=1e-5, what="linearity")
     # symmetry of A_hat: <u, A v> = <A u, v> in fp64
     u64, v64 = xd.double(), z.double()
     a = (u64 * ops.spmm_norm_act(g, z, 1.0).double()).sum()
@@ -632,7 +632,7 @@ def test_propagation_backward_matches_oracle_autograd():
         ((torch.cat([tu, ti]) * r1).sum() + (torch.cat([hu, hi]) * r2).sum()).backward()
         want = torch.cat([ue.grad, ie.grad])
         # isolated nodes get d/dx of x/eps = 1e12 * g from F.normalize; compare those rows relatively too
-        assert_rows_close(m.embedding_table.grad, want, rtol=2e-5, what=f"d e0 {kw}")
+        assert_rows_close(m.embedding_table.grad, want, rtol=1e-5, what=f"d e0 {kw}")
 
 
 def test_rec_cal_loss_gradients_golden():
@@ -687,7 +687,7 @@ def test_nc_propagation_backward_matches_oracle_autograd():
         edges = [(T(m.tocoo().row.astype(np.int64)), T(m.tocoo().col.astype(np.int64))) for m in mats]
         s1, s2, tgt = O.nc_forward(edges, e_cpu, eye, zero, 3)
         ((tgt * rs[0]).sum() + (s1 * rs[1]).sum() + (s2 * rs[2]).sum()).backward()
-        assert_rows_close(embed.grad, e_cpu.grad, rtol=2e-5, what=f"nc d embed {kw}")
+        assert_rows_close(embed.grad, e_cpu.grad, rtol=1e-5, what=f"nc d embed {kw}")
         for o, want in zip(sums, (tgt, s1, s2)):
             assert_rows_close(o.detach(), want.detach(), what="nc forward under autograd")
 
@@ -710,7 +710,7 @@ def test_nc_cal_loss_gradients_golden():
     onehot = torch.zeros(NA, 4)
     onehot[torch.arange(NA), T(load("dblp_graph.npz")["labels"])] = 1.0
     nll, diff = model.cal_loss(dev(fx["cl_ancs"]), dev(onehot), adjs, dev(features), dev(fx["tr_ts"]), dev(fx["tr_noise"]))
-    np.testing.assert_allclose([float(nll.detach()), float(diff.detach())], fx["tr_losses"], rtol=2e-5)
+    np.testing.assert_allclose([float(nll.detach()), float(diff.detach())], fx["tr_losses"], rtol=1e-5)
     (nll + diff).backward()
     got = {"transform_layer_weight": model.transform_layer.weight, "transform_layer_bias": model.transform_layer.bias,
            "dense_weight": model.dense.weight, "dense_bias": model.dense.bias,
@@ -873,7 +873,7 @@ def test_lds_resident_small_side_matches_oracle():
     ue_, ie_ = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
     tu, ti, hu, hi = O.rec_forward(edges_t(*inter[0], nu), [edges_t(*b, nu) for b in inter[1:]], ue_, ie_, 2)
     ((torch.cat([tu, ti]) * r1).sum() + (torch.cat([hu, hi]) * r2).sum()).backward()
-    assert_rows_close(m.embedding_table.grad, torch.cat([ue_.grad, ie_.grad]), rtol=2e-5, what="lds path d e0")
+    assert_rows_close(m.embedding_table.grad, torch.cat([ue_.grad, ie_.grad]), rtol=1e-5, what="lds path d e0")
 
 
 def test_sharded_lds_graphs_split_layer_calls():
@@ -953,7 +953,7 @@ def test_ijcai_size_predict_against_oracle():
     for got, base, h, dn, nm in ((pu, tu, hu, m.usr_denoiser, "users"), (pi, ti, hi, m.item_denoiser, "items")):
         rows = torch.randperm(h.shape[0], generator=gen)[:96]
         want = base[rows] + O.p_sample(tab, _oracle_weights(dn), h[rows], 0)
-        assert_rows_close(got[rows.to(DEV)], want, rtol=2e-5, what="ijcai predict " + nm)
+        assert_rows_close(got[rows.to(DEV)], want, rtol=1e-5, what="ijcai predict " + nm)
     assert torch.isfinite(pu).all() and torch.isfinite(pi).all()
 
 
@@ -985,6 +985,10 @@ def test_tmall_size_forward_and_cal_loss_against_oracle():
     batch, reg = float(m.args.batch), float(m.args.reg)
     loss, bpr, regl, diff = m.cal_loss(dev(ancs), dev(poss), dev(negs), dev(ts_u), dev(noise_u), dev(ts_i), dev(noise_i))
     loss.backward()
+    # The oracle in fp32, like the reference.  (Its fp64 evaluation is no better yardstick for this gradient: the
+    # hottest items' rows add a few thousand terms, a handful of their second-layer pre-activations lie within fp32
+    # rounding of zero, and LeakyReLU's derivative jumps there -- the fp64 and fp32 oracles differ by up to 0.2 of the
+    # row scale in about 2 400 rows that neighbour such an item, while kernels and fp32 oracle agree to 2.4e-5.)
     ue_, ie_ = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
     wu, wi = _oracle_weights(m.usr_denoiser), _oracle_weights(m.item_denoiser)
     for w in (wu, wi):
@@ -1110,7 +1114,7 @@ def test_layer_random_graphs_and_schedules(seed):
     h1 = O.gcn_layer(s, d, n, x * 0.1, slope=0.5)
     h2 = O.gcn_layer(s, d, n, h1, slope=0.5)
     want = x * 0.1 + torch.nn.functional.normalize(h1, p=2, dim=1) + torch.nn.functional.normalize(h2, p=2, dim=1)
-    assert_rows_close(acc, want, rtol=2e-5, what=what + " two layers")
+    assert_rows_close(acc, want, rtol=1e-5, what=what + " two layers")
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -1142,7 +1146,7 @@ def test_propagation_backward_random_graphs(seed):
     tu, ti, hu, hi = O.rec_forward(edges_t(*inter[0], nu), [edges_t(*b, nu) for b in inter[1:]], ue_, ie_, 2)
     assert_rows_close(ui, torch.cat([tu, ti]), what=f"seed {seed} forward")
     ((torch.cat([tu, ti]) * r1.double()).sum() + (torch.cat([hu, hi]) * r2.double()).sum()).backward()
-    assert_rows_close(m_.embedding_table.grad, torch.cat([ue_.grad, ie_.grad]), rtol=2e-5,
+    assert_rows_close(m_.embedding_table.grad, torch.cat([ue_.grad, ie_.grad]), rtol=1e-5,
                       what=f"seed {seed} d e0 ({nu} x {ni}, {knobs})")
 
 
@@ -1174,7 +1178,7 @@ def test_dense_graphs_take_the_bitmap_path(n, density, directed):
     h1 = O.gcn_layer(s_, d_, n, x * 0.1, slope=0.5)
     h2 = O.gcn_layer(s_, d_, n, h1, slope=0.5)
     want = x * 0.1 + torch.nn.functional.normalize(h1, p=2, dim=1) + torch.nn.functional.normalize(h2, p=2, dim=1)
-    assert_rows_close(acc, want, rtol=2e-5, what="dense two layers")
+    assert_rows_close(acc, want, rtol=1e-5, what="dense two layers")
     # same bits on a second launch
     acc2 = torch.empty_like(acc)
     ops.gcn_layer_batched([ops.LayerTask(g, e1, None, e0, acc2, DG_IN_PRESCALED | DG_ACC_REBUILD, 0.5)])
@@ -1212,4 +1216,4 @@ def test_dense_graphs_backward_matches_oracle_autograd():
     ((tgt * rs[0].double()).sum() + (s1 * rs[1].double()).sum() + (s2 * rs[2].double()).sum()).backward()
     for o, want in zip(sums, (tgt, s1, s2)):
         assert_rows_close(o.detach(), want.detach(), what="dense nc forward")
-    assert_rows_close(embed.grad, e_cpu.grad, rtol=2e-5, what="dense nc d embed")
+    assert_rows_close(embed.grad, e_cpu.grad, rtol=1e-5, what="dense nc d embed")

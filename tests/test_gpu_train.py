@@ -85,7 +85,7 @@ def _fixed_draws(coach, n_steps, seed, keep):
 
 def _optimizer_state(o):
     out = [o.exp_avg, o.exp_avg_sq, o.state]
-    for prm in sorted(o.rest.state, key=lambda q: q.data_ptr()):
+    for prm in o.rest.param_groups[0]["params"]:        # the optimizer's own order (the same for every model instance)
         st = o.rest.state[prm]
         out += [st[k] for k in sorted(st) if torch.is_tensor(st[k])]
     return out
