@@ -410,6 +410,17 @@ def bench_sharded(args, rank: int, world: int, device, backend=None) -> Optional
     per_rank_bytes = layer_bytes_global / world
     achieved = per_rank_bytes / (layer_ms * 1e-3) / 1e9
     value = L * sum(nnz) * args.steps / elapsed
+    # What one layer of this forward pass cannot avoid moving, per graph (mean over the layers, the rank's share):
+    # user-row shards -- a 64-B record per user row, every user row of the layer's input read once by the item side
+    # (256 B) plus a byte per link, the activation written (all layers but the last), from layer 2 on the running sum
+    # rebuilt from e0 and the stored activation and written (3 x 256 B); row blocks -- the general kernel's streams.
+    if row_blocks:
+        per_layer = [sum(4 * e + n_total * (128 + 256 + (256 if l < L - 1 else 0) + (0 if l == 0 and L >= 2 else 768))
+                         for e in nnz) for l in range(L)]
+    else:
+        per_layer = [sum(wl.n_user * (64 + 256 + (256 if l < L - 1 else 0) + (0 if l == 0 and L >= 2 else 768)) + e // 2
+                         for e in nnz) for l in range(L)]
+    bytes_compulsory = float(np.mean(per_layer)) / world
 
     # The same workload on ONE GPU, measured by rank 0 in this very run (the other ranks wait), so that the
     # scaling of this line can be read without a second run.
@@ -444,7 +455,9 @@ def bench_sharded(args, rank: int, world: int, device, backend=None) -> Optional
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": "one sharded propagation layer on rank 0 (propagation kernels + "
                          "exchange + partial_finalize_kernel; user-row shards: a forward pass / its layers)",
-                         "bytes_per_launch": per_rank_bytes, "ms_per_launch": layer_ms},
+                         "bytes_per_launch": per_rank_bytes, "ms_per_launch": layer_ms,
+                         "bytes_compulsory": bytes_compulsory,
+                         "frac_compulsory": bytes_compulsory / (layer_ms * 1e-3) / 1e9 / 8000.0},
         }
         if single is not None:
             res["config"]["same_workload_1gpu_edges_per_s"] = single
