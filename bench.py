@@ -295,7 +295,7 @@ def main():
         elif workload.startswith("predict_"):
             res = bench_next.bench_predict(workload[8:], args.steps, args.warmup, not args.no_cpu_baseline)
         elif workload.startswith("nc_train"):
-            res = bench_next.bench_nc_train(args.steps, args.warmup, not args.no_cpu_baseline)
+            res = bench_next.bench_nc_train(args.steps, args.warmup, not args.no_cpu_baseline, not args.no_graph)
         elif workload.startswith("nc_dblp"):
             res = bench_next.bench_nc_dblp(args.steps, args.warmup, not args.no_cpu_baseline)
         elif workload.startswith("negsample_"):

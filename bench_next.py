@@ -234,16 +234,18 @@ def _nc_dblp_setup():
     return dev, NA, mats, adjs, features, model, torch.from_numpy(np.asarray(g["labels"])).long()
 
 
-def bench_nc_train(steps: int, warmup: int, cpu_baseline: bool):
+def bench_nc_train(steps: int, warmup: int, cpu_baseline: bool, use_graph: bool = True):
     """One training step of DiffGraph_NC on DBLP (DiffGraph_NC/main.py:372-386): cal_loss over a batch of 8 labelled
     authors (3 x 3 propagation layers, q_sample + denoiser + SNR loss, classifier, NLL), backward, Adam."""
     dev, NA, mats, adjs, features, model, labels = _nc_dblp_setup()
+    model.train()      # the reference never leaves training mode (no .eval() in DiffGraph_NC/main.py): dropout is on
     fd = features.to(dev)
     onehot = torch.zeros(NA, 4, device=dev)
     onehot[torch.arange(NA, device=dev), labels.to(dev)] = 1.0
     gen = torch.Generator().manual_seed(1)
     ancs = torch.sort(torch.randperm(NA, generator=gen)[: model.args.batch])[0].to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=3e-3, weight_decay=0)
+    # capturable: Adam's step counter lives on the device, so the whole step can be recorded as one HIP graph
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3, weight_decay=0, capturable=use_graph)
 
     def step():
         nll, diff = model.cal_loss(ancs, onehot, adjs, fd)
@@ -251,8 +253,24 @@ def bench_nc_train(steps: int, warmup: int, cpu_baseline: bool):
         (nll + diff).backward()
         opt.step()
         return nll, diff
-    wall_ms, dev_ms = _timed(step, steps, warmup)
-    nll, diff = step()
+    if use_graph:
+        # the ~60 launches of a step recorded once and replayed: the timesteps and the noise come from torch's
+        # generator, whose offset a replay advances, so every replay trains on fresh draws like an eager step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            losses = step()
+        wall_ms, dev_ms = _timed(graph.replay, steps, warmup)
+        graph.replay()
+        nll, diff = losses
+    else:
+        wall_ms, dev_ms = _timed(step, steps, warmup)
+        nll, diff = step()
     with torch.no_grad():
         embed = model.transform_layer(fd)
         _, prop_ms = _timed(lambda: model.propagate(adjs, embed), max(steps, 10), 3)
@@ -265,7 +283,8 @@ def bench_nc_train(steps: int, warmup: int, cpu_baseline: bool):
            "data": "DBLP edge lists and author features (tests/golden/dblp_graph.npz), random-init weights",
            "config": {"workload": "nc_train_dblp: APA / APCPA / APTPA author graphs, batch of 8 authors", "authors": NA,
                       "directed_edges_per_graph": nnz, "layers": L, "device_ms_per_step": dev_ms,
-                      "loss": [float(nll.detach()), float(diff.detach())], "launch": "eager"},
+                      "loss": [float(nll.detach()), float(diff.detach())],
+                      "launch": "hip-graph replay" if use_graph else "eager"},
            "roofline": {"bound": "hbm", "achieved": L * layer_bytes / (prop_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": L * layer_bytes / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "kernel": "gcn_layer_kernel + hub_reduce_kernel, forward propagation: 3 layers x 3 graphs",

@@ -235,17 +235,19 @@ class GaussianDiffusion(nn.Module):
         return ops.p_sample_loop_batched(prepared, self._dev("posterior_mean_coef1", dev),
                                          self._dev("posterior_mean_coef2", dev))
 
-    def training_losses2(self, model, targetEmbeds, x_start, batch, ts=None, noise=None, keep_mask=None):  # Model.py:348-366
-        row_loss, out = self.training_losses_rows(model, targetEmbeds, x_start, ts, noise, keep_mask)
+    def training_losses2(self, model, targetEmbeds, x_start, batch, ts=None, noise=None, keep_mask=None,
+                         validate=None):  # Model.py:348-366
+        row_loss, out = self.training_losses_rows(model, targetEmbeds, x_start, ts, noise, keep_mask, validate)
         return row_loss[batch], out
 
-    def training_losses_rows(self, model, targetEmbeds, x_start, ts=None, noise=None, keep_mask=None):
+    def training_losses_rows(self, model, targetEmbeds, x_start, ts=None, noise=None, keep_mask=None, validate=None):
         """training_losses2 before its final `[batch]` gather (Model.py:348-365): the fp64 SNR-weighted loss of
         EVERY row and the denoiser output.  With `model` in training mode its dropout (Model.py:223-224) is applied
         inside the kernels: to the elements `keep_mask` ([n, 64] bool / uint8) keeps, or to a fresh draw."""
         n = x_start.size(0)
         dev = x_start.device
-        validate = ts is not None  # caller-supplied timesteps are range-checked (one host sync)
+        if validate is None:
+            validate = ts is not None  # caller-supplied timesteps are range-checked (one host sync) unless told otherwise
         if ts is None:
             ts = torch.randint(0, self.steps, (n,), device=dev).long()
         if noise is None and self.noise_scale != 0:

@@ -182,11 +182,14 @@ class HGDM(nn.Module):
         target, s1, s2 = self.propagate(he_adjs, embed)
         return s1, s2, target
 
-    def cal_loss(self, ancs, label, he_adjs, initial_feature, ts=None, noise=None, keep_mask=None):  # Model.py:75-89
+    def cal_loss(self, ancs, label, he_adjs, initial_feature, ts=None, noise=None, keep_mask=None,
+                 validate=None):  # Model.py:75-89
+        """`ts` / `noise` / `keep_mask`: the draws of training_losses2 handed in instead of drawn; `validate=False`
+        skips the range check of caller-supplied timesteps (a host synchronisation a recorded step cannot have)."""
         s1, s2, target_embedding = self.forward(he_adjs, initial_feature)
         source_embeddings = s1 + s2
         diff_loss, diff_embeddings = self.diffusion_model.training_losses2(
-            self.user_denoise_model, target_embedding, source_embeddings, ancs, ts, noise, keep_mask)
+            self.user_denoise_model, target_embedding, source_embeddings, ancs, ts, noise, keep_mask, validate)
         diff_loss = diff_loss.mean()
         all_embeddings = target_embedding + diff_embeddings
         ancs = ancs.long().contiguous()

@@ -221,3 +221,73 @@ def test_batch_sizes_that_divide_the_data_or_exceed_it(batch):
             assert sorted(c._graphs) == [(min(batch, 186), False)]
     for a, b in zip(res[True], res[False]):
         assert np.isfinite(a["Loss"]) and a == b
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_nc_step_replayed_as_a_graph_equals_the_eager_step_bit_for_bit(mode):
+    """One DiffGraph_NC training step (DiffGraph_NC/main.py:378-386: cal_loss, backward, Adam) over one sparse and two
+    dense author graphs, recorded as a HIP graph and replayed five times, against five eager steps from the same
+    start with the same timesteps / noise / dropout mask: the losses, every parameter and Adam's moments are the same
+    bits."""
+    n, f = 700, 40
+    rng = np.random.default_rng(5)
+    mats = []
+    for dens in (0.01, 0.3, 0.45):
+        a = rng.random((n, n)) < dens
+        mats.append(sp.csr_matrix((a | a.T).astype(np.float32)))
+    gen = torch.Generator().manual_seed(13)
+    feats = torch.rand(n, f, generator=gen).to(DEV)
+    onehot = torch.zeros(n, 4, device=DEV)
+    onehot[torch.arange(n), torch.randint(0, 4, (n,), generator=gen)] = 1.0
+    ancs = torch.randperm(n, generator=gen)[:8].to(DEV)
+    ts = torch.randint(0, 200, (n,), generator=gen).to(DEV)
+    noise = torch.randn(n, 64, generator=gen).to(DEV)
+    keep = (torch.rand(n, 64, generator=gen) >= 0.5).to(torch.uint8).to(DEV) if mode == "train" else None
+    out = {}
+    for use_graph in (True, False):
+        adjs = [dg.CSRGraph.from_scipy(m) for m in mats]
+        torch.manual_seed(17)
+        model = dg.nc.HGDM(f).train(mode == "train")
+        opt = torch.optim.Adam(model.parameters(), lr=3e-3, weight_decay=0, capturable=True)
+        start = [p.detach().clone() for p in model.parameters()]
+
+        def step():
+            nll, diff = model.cal_loss(ancs, onehot, adjs, feats, ts, noise, keep, validate=False)
+            opt.zero_grad(set_to_none=True)
+            (nll + diff).backward()
+            opt.step()
+            return torch.stack([nll.detach().double(), diff.detach().double()])
+        losses = []
+        if use_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                res = step()
+            torch.cuda.synchronize()
+            with torch.no_grad():       # back to the start: parameters, moments and Adam's device-side step counter
+                for p, q in zip(model.parameters(), start):
+                    p.copy_(q)
+                for st in opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            for _ in range(5):
+                graph.replay()
+                torch.cuda.synchronize()
+                losses.append(res.clone())
+        else:
+            for _ in range(5):
+                losses.append(step().clone())
+        out[use_graph] = (losses, [p.detach().clone() for p in model.parameters()],
+                          [st[k].clone() for p in opt.param_groups[0]["params"] for st in [opt.state[p]] for k in sorted(st)])
+    (gl, gp, gs), (el, ep, es) = out[True], out[False]
+    assert all(bool(torch.isfinite(a).all()) for a in gl) and float(gl[-1].sum()) != float(gl[0].sum())
+    for a, b in zip(gl, el):
+        assert torch.equal(a, b), (a, b)
+    for a, b in zip(gp + gs, ep + es):
+        assert torch.equal(a, b)
