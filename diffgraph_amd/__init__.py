@@ -10,6 +10,7 @@ Python classes that keep the reference's call signatures:
     evaluate.AllRankTestData, testEpoch, calcRes   DiffGraph-Rec/DataHandler.py:250-272, main.py:136-187
     sampling.PairwiseTrnData          DiffGraph-Rec/DataHandler.py:274-296
     train.Coach                       DiffGraph-Rec/main.py:34-215 (trainEpoch, testEpoch, run)
+    train_nc.NCCoach                  DiffGraph_NC/main.py:333-449 (prepareModel, trainEpoch, testEpoch, run)
     metapath.compose_he_adjs          DiffGraph_NC/DataHandler.py:147-174
 
 Importing the package does not load the shared library; the first op does, and raises
@@ -21,7 +22,7 @@ from .layers import DGLLayer, UUGCNLayer  # noqa: F401
 from .diffusion import Denoise, GaussianDiffusion  # noqa: F401
 from . import model_rec as rec  # noqa: F401
 from . import model_nc as nc  # noqa: F401
-from . import data, evaluate, io, metapath, ops, optim, sampling, train  # noqa: F401
+from . import data, evaluate, io, metapath, ops, optim, sampling, train, train_nc  # noqa: F401
 
 __all__ = ["CSRGraph", "DGLLayer", "UUGCNLayer", "Denoise", "GaussianDiffusion", "rec", "nc", "ops", "data",
            "DiffGraphHipError"]

@@ -236,11 +236,12 @@ class GaussianDiffusion(nn.Module):
                                          self._dev("posterior_mean_coef2", dev))
 
     def training_losses2(self, model, targetEmbeds, x_start, batch, ts=None, noise=None, keep_mask=None,
-                         validate=None):  # Model.py:348-366
-        row_loss, out = self.training_losses_rows(model, targetEmbeds, x_start, ts, noise, keep_mask, validate)
+                         validate=None, drop_seed=None):  # Model.py:348-366
+        row_loss, out = self.training_losses_rows(model, targetEmbeds, x_start, ts, noise, keep_mask, validate, drop_seed)
         return row_loss[batch], out
 
-    def training_losses_rows(self, model, targetEmbeds, x_start, ts=None, noise=None, keep_mask=None, validate=None):
+    def training_losses_rows(self, model, targetEmbeds, x_start, ts=None, noise=None, keep_mask=None, validate=None,
+                             drop_seed=None):
         """training_losses2 before its final `[batch]` gather (Model.py:348-365): the fp64 SNR-weighted loss of
         EVERY row and the denoiser output.  With `model` in training mode its dropout (Model.py:223-224) is applied
         inside the kernels: to the elements `keep_mask` ([n, 64] bool / uint8) keeps, or to a fresh draw."""
@@ -254,7 +255,7 @@ class GaussianDiffusion(nn.Module):
             noise = torch.randn_like(x_start)
         norm = bool(model.norm)
         xs = x_start.contiguous()
-        drop = dropout_args([model], keep_mask, dev)
+        drop = dropout_args([model], keep_mask, dev, drop_seed)
         if torch.is_grad_enabled() and (xs.requires_grad or targetEmbeds.requires_grad
                                         or any(q.requires_grad for q in model.parameters())):
             return _DiffusionLossFn.apply(

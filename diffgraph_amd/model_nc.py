@@ -24,7 +24,7 @@ from .layers import UUGCNLayer
 
 DEFAULT_ARGS = SimpleNamespace(latdim=64, gcn_layer=3, uugcn_layer=3, dims="[64]", d_emb_size=8, norm=True, steps=200,
                                noise_scale=1e-5, noise_min=1e-4, noise_max=1e-3, sampling_steps=0,
-                               batch=8)  # DiffGraph_NC/params.py:5-68
+                               batch=8, lr=3e-3, epoch=10)  # DiffGraph_NC/params.py:5-68
 
 
 class _LinearFn(torch.autograd.Function):
@@ -183,13 +183,14 @@ class HGDM(nn.Module):
         return s1, s2, target
 
     def cal_loss(self, ancs, label, he_adjs, initial_feature, ts=None, noise=None, keep_mask=None,
-                 validate=None):  # Model.py:75-89
-        """`ts` / `noise` / `keep_mask`: the draws of training_losses2 handed in instead of drawn; `validate=False`
-        skips the range check of caller-supplied timesteps (a host synchronisation a recorded step cannot have)."""
+                 validate=None, drop_seed=None):  # Model.py:75-89
+        """`ts` / `noise` / `keep_mask`: the draws of training_losses2 handed in instead of drawn (`drop_seed`, int64[1]
+        on the device: the key the kernels draw the dropout mask from when no mask is given); `validate=False` skips
+        the range check of caller-supplied timesteps (a host synchronisation a recorded step cannot have)."""
         s1, s2, target_embedding = self.forward(he_adjs, initial_feature)
         source_embeddings = s1 + s2
         diff_loss, diff_embeddings = self.diffusion_model.training_losses2(
-            self.user_denoise_model, target_embedding, source_embeddings, ancs, ts, noise, keep_mask, validate)
+            self.user_denoise_model, target_embedding, source_embeddings, ancs, ts, noise, keep_mask, validate, drop_seed)
         diff_loss = diff_loss.mean()
         all_embeddings = target_embedding + diff_embeddings
         ancs = ancs.long().contiguous()

@@ -291,3 +291,61 @@ def test_nc_step_replayed_as_a_graph_equals_the_eager_step_bit_for_bit(mode):
         assert torch.equal(a, b), (a, b)
     for a, b in zip(gp + gs, ep + es):
         assert torch.equal(a, b)
+
+
+def _nc_handler(n=700, f=40, seed=5):
+    rng = np.random.default_rng(seed)
+    mats = []
+    for dens in (0.01, 0.3, 0.45):
+        a = rng.random((n, n)) < dens
+        mats.append(sp.csr_matrix((a | a.T).astype(np.float32)))
+    gen = torch.Generator().manual_seed(13)
+    labels = torch.zeros(n, 4)
+    labels[torch.arange(n), torch.randint(0, 4, (n,), generator=gen)] = 1.0
+    # features that carry the label, so that a few epochs of training show in the accuracy
+    feats = torch.rand(n, f, generator=gen) * 0.2 + labels.repeat(1, f // 4)
+    perm = rng.permutation(n)
+    return SimpleNamespace(feature_list=feats, labels=labels, he_adjs=[dg.CSRGraph.from_scipy(m) for m in mats],
+                           train_idx=[perm[:60], perm[:101]], val_idx=[perm[200:300]] * 2, test_idx=[perm[300:]] * 2)
+
+
+def test_nc_coach_replayed_epochs_equal_eager_epochs_bit_for_bit():
+    """NCCoach (DiffGraph_NC/main.py:364-449): two epochs over 101 labelled authors in batches of 8 (12 full batches
+    and a short one of 5 -- two recordings), dropout on as in the reference, replayed against eagerly launched with the
+    same seed: the same epoch losses, parameters, Adam moments and test metrics; and the model has learnt something."""
+    from diffgraph_amd.train_nc import NCCoach
+    out = {}
+    for use_graph in (True, False):
+        torch.manual_seed(3)
+        c = NCCoach(_nc_handler(), device=DEV, use_graph=use_graph, seed=7)
+        c.prepareModel()
+        assert c.model.training
+        eps = [c.trainEpoch(1) for _ in range(2)]
+        val, test = c.testEpoch(1)
+        if use_graph:
+            assert sorted(c._graphs) == [(5, True), (8, True)]
+        out[use_graph] = (eps, [p.detach().clone() for p in c.model.parameters()],
+                          [st[k].clone() for p in c.opt.param_groups[0]["params"] for st in [c.opt.state[p]] for k in sorted(st)],
+                          (float(val["acc"]), val["macro"], val["micro"], float(test["acc"]), test["macro"], test["micro"]),
+                          test["logits"].clone())
+    (g_eps, g_p, g_s, g_m, g_l), (e_eps, e_p, e_s, e_m, e_l) = out[True], out[False]
+    assert all(np.isfinite(v) for ep in g_eps for v in ep.values()) and g_eps == e_eps, (g_eps, e_eps)
+    assert g_eps[1]["bceLoss"] < g_eps[0]["bceLoss"]
+    for a, b in zip(g_p + g_s + [g_l], e_p + e_s + [e_l]):
+        assert torch.equal(a, b)
+    assert g_m == e_m and g_m[3] > 0.5 and g_l.shape == (400, 4)      # four balanced classes: chance is 0.25
+    assert float(g_s[2]) == float(e_s[2]) == 26.0       # Adam's step count (keys sorted: exp_avg, exp_avg_sq, step): 2 x 13 steps, warm-ups undone
+
+
+def test_nc_coach_run_and_checkpoint(tmp_path):
+    from diffgraph_amd.train_nc import NCCoach
+    torch.manual_seed(3)
+    c = NCCoach(_nc_handler(), device=DEV, seed=1)
+    res = c.run(ratio=0, epochs=3, log=lambda s: None)
+    assert set(res) == {"acc", "macro", "macro_val", "micro"} and len(c.metrics["bceLoss"]) == 3 and 0.25 < res["acc"] <= 1.0
+    path = str(tmp_path / "nc.pt")
+    c.saveModel(path)
+    d = NCCoach(_nc_handler(), device=DEV, seed=1)
+    d.loadModel(path)
+    a, b = c.testEpoch(0)[1], d.testEpoch(0)[1]
+    assert torch.equal(a["logits"], b["logits"]) and a["macro"] == b["macro"]

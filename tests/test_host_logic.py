@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 from diffgraph_amd import data as dgdata
@@ -53,3 +54,17 @@ def test_nothing_shipped_imports_the_oracle_by_itself():
             "bad = [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]; assert not bad, bad" % ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-1500:]
+
+
+def test_f1_scores_equal_sklearn():
+    """train_nc.f1_scores (confusion matrix) against sklearn.metrics.f1_score, which the reference calls
+    (DiffGraph_NC/Utils/Utils.py:121-122): classes that never occur, classes only predicted, perfect and empty cases."""
+    from sklearn.metrics import f1_score
+    from diffgraph_amd.train_nc import f1_scores
+    rng = np.random.default_rng(4)
+    cases = [(rng.integers(0, 4, 300), rng.integers(0, 4, 300)), (rng.integers(0, 2, 50), rng.integers(0, 4, 50)),
+             (rng.integers(1, 3, 40), rng.integers(0, 2, 40)), (np.arange(4), np.arange(4)), (np.zeros(7, int), np.ones(7, int))]
+    for y, p in cases:
+        macro, micro = f1_scores(torch.from_numpy(y), torch.from_numpy(p), 4)
+        assert macro == pytest.approx(f1_score(y, p, average="macro"), abs=1e-12)
+        assert micro == pytest.approx(f1_score(y, p, average="micro"), abs=1e-12)
