@@ -84,6 +84,9 @@ SIGNATURES = {
                                   C.POINTER(C.c_void_p)]),
     "dg_graph_create_ex": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.POINTER(C.c_void_p)]),
+    "dg_graph_create_weighted": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.POINTER(C.c_void_p)]),
+    "dg_graph_num_rows": (C.c_int32, [C.c_void_p]),
     "dg_graph_destroy": (None, [C.c_void_p]),
     "dg_graph_num_nodes": (C.c_int32, [C.c_void_p]),
     "dg_graph_num_edges": (C.c_int64, [C.c_void_p]),

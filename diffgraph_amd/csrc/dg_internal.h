@@ -112,6 +112,8 @@ struct dg_graph {
   int32_t n = 0;
   int64_t nnz = 0;
   int symmetric = 0;
+  int weighted = 0;           // dg_graph_create_weighted: colscale holds caller-given weights, rows [0, n_rows) are computed
+  int32_t n_rows = 0;
   int32_t group_max = 0, seg_len = 0;
   float *dinv_src = nullptr;  // [n] max(out_deg,1)^-1/2
   float *dinv_dst = nullptr;  // [n] max(in_deg,1)^-1/2

@@ -45,7 +45,9 @@ struct HostCsr {
 
 // CSR over `row` with ascending `col` inside each row: two stable counting sorts
 // (by col, then by row), O(n + nnz).
-void build_csr(int32_t n, int64_t nnz, const int32_t *row, const int32_t *col, HostCsr &out) {
+// `perm` (optional) receives, per CSR position, the index of the edge it came from.
+void build_csr(int32_t n, int64_t nnz, const int32_t *row, const int32_t *col, HostCsr &out,
+               std::vector<int32_t> *perm = nullptr) {
   std::vector<int64_t> cnt((size_t)n + 1, 0);
   for (int64_t e = 0; e < nnz; ++e) cnt[(size_t)col[e] + 1]++;
   for (int32_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
@@ -61,9 +63,12 @@ void build_csr(int32_t n, int64_t nnz, const int32_t *row, const int32_t *col, H
   out.colidx.resize((size_t)nnz);
   {
     std::vector<int64_t> pos(rp.begin(), rp.end() - 1);
+    if (perm) perm->resize((size_t)nnz);
     for (int64_t k = 0; k < nnz; ++k) {
       int32_t e = by_col[(size_t)k];
-      out.colidx[(size_t)pos[row[e]]++] = col[e];
+      const int64_t at = pos[row[e]]++;
+      out.colidx[(size_t)at] = col[e];
+      if (perm) (*perm)[(size_t)at] = e;
     }
   }
   for (int32_t i = 0; i <= n; ++i) out.rowptr[i] = (int32_t)rp[i];
@@ -475,7 +480,7 @@ extern "C" int dg_graph_create_ex(int32_t n, int64_t nnz, const int32_t *src, co
   }
 
   dg_graph *g = new dg_graph();
-  g->n = n; g->nnz = nnz; g->symmetric = symmetric ? 1 : 0;
+  g->n = n; g->nnz = nnz; g->symmetric = symmetric ? 1 : 0; g->n_rows = n;
   g->group_max = group_max; g->seg_len = seg_len;
   hipError_t e = hipGetDevice(&g->device);
   if (e == hipSuccess) e = upload(dsrc, &g->dinv_src);
@@ -501,6 +506,57 @@ extern "C" int dg_graph_create_ex(int32_t n, int64_t nnz, const int32_t *src, co
   return 0;
 }
 
+// A rectangular operator with a weight per entry, run by the same row schedule and kernels as a graph:
+// out[r] = sum over the entries (r, c) of weight * x[c].  The handle has max(n_rows, n_cols) nodes of which the first
+// n_rows are computed; both degree norms are 1, the weights sit where a graph keeps its sources' norms.
+extern "C" int dg_graph_create_weighted(int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *row, const int32_t *col,
+                                        const float *weight, int32_t group_max, int32_t seg_len, dg_graph **out) {
+  if (!out) return dg_fail(DG_ERR_ARG, "dg_graph_create_weighted: out is NULL");
+  *out = nullptr;
+  if (n_rows <= 0 || n_cols <= 0) return dg_fail(DG_ERR_ARG, "dg_graph_create_weighted: empty shape %d x %d", n_rows, n_cols);
+  if (nnz < 0 || (nnz > 0 && (!row || !col || !weight))) return dg_fail(DG_ERR_ARG, "dg_graph_create_weighted: bad entry arrays");
+  if (nnz >= (int64_t)INT32_MAX)
+    return dg_fail(DG_ERR_SIZE, "dg_graph_create_weighted: %lld entries exceed the int32 CSR limit", (long long)nnz);
+  const int32_t n = std::max(n_rows, n_cols);
+  if ((int64_t)n * DG_D * 4 >= ((int64_t)1 << 32))
+    return dg_fail(DG_ERR_SIZE, "dg_graph_create_weighted: %d rows exceed the 4 GiB table limit of the gather path", n);
+  if (group_max <= 0) group_max = 64;
+  if (seg_len <= 0) seg_len = 256;
+  if (seg_len < 64 || seg_len % 64 != 0)
+    return dg_fail(DG_ERR_ARG, "dg_graph_create_weighted: seg_len must be a positive multiple of 64 (got %d)", seg_len);
+  if (group_max > seg_len) group_max = seg_len;
+  for (int64_t e = 0; e < nnz; ++e)
+    if (row[e] < 0 || row[e] >= n_rows || col[e] < 0 || col[e] >= n_cols)
+      return dg_fail(DG_ERR_ARG, "dg_graph_create_weighted: entry %lld (%d, %d) outside %d x %d", (long long)e, row[e], col[e],
+                     n_rows, n_cols);
+  HostCsr f;
+  std::vector<int32_t> perm;
+  build_csr(n, nnz, row, col, f, &perm);
+  f.colscale.resize((size_t)nnz);
+  for (int64_t p = 0; p < nnz; ++p) f.colscale[(size_t)p] = weight[perm[(size_t)p]];
+  std::vector<char> owned((size_t)n, 0);
+  std::fill(owned.begin(), owned.begin() + n_rows, 1);
+  build_schedule(n, group_max, seg_len, f, &owned);   // (an ownership list keeps it on the gather path)
+  const std::vector<float> ones((size_t)n, 1.0f);
+  dg_graph *g = new dg_graph();
+  g->n = n; g->nnz = nnz; g->symmetric = 1; g->weighted = 1; g->n_rows = n_rows;
+  g->group_max = group_max; g->seg_len = seg_len;
+  hipError_t e = hipGetDevice(&g->device);
+  if (e == hipSuccess) e = upload(ones, &g->dinv_src);
+  if (e == hipSuccess) e = upload(ones, &g->dinv_dst);
+  if (e == hipSuccess) e = upload_csr(f, g->fwd);
+  if (e == hipSuccess) {
+    g->bwd = g->fwd;
+    e = hipMalloc((void **)&g->slab, std::max<size_t>((size_t)g->fwd.n_seg, 1) * DG_D * sizeof(float));
+  }
+  if (e != hipSuccess) {
+    dg_graph_destroy(g);
+    return dg_fail((int)e, "dg_graph_create_weighted: device allocation/copy failed: %s", hipGetErrorString(e));
+  }
+  *out = g;
+  return 0;
+}
+
 extern "C" void dg_graph_destroy(dg_graph *g) {
   if (!g) return;
   if (!g->symmetric) free_csr(g->bwd);
@@ -510,6 +566,7 @@ extern "C" void dg_graph_destroy(dg_graph *g) {
 }
 
 extern "C" int32_t dg_graph_num_nodes(const dg_graph *g) { return g ? g->n : 0; }
+extern "C" int32_t dg_graph_num_rows(const dg_graph *g) { return g ? g->n_rows : 0; }
 extern "C" int64_t dg_graph_num_edges(const dg_graph *g) { return g ? g->nnz : 0; }
 extern "C" int dg_graph_is_symmetric(const dg_graph *g) { return g ? g->symmetric : 0; }
 

@@ -712,6 +712,8 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   if (in.e_out == in.x) return dg_fail(DG_ERR_ARG, "layer task: e_out must not alias x");
   if ((in.flags & DG_ACC_REBUILD) && (!(in.flags & DG_IN_PRESCALED) || !in.acc_out))
     return dg_fail(DG_ERR_ARG, "layer task: DG_ACC_REBUILD needs DG_IN_PRESCALED and acc_in/acc_out");
+  if (g->weighted && (transpose || (in.flags & (DG_IN_PRESCALED | DG_EPI_BWD))))
+    return dg_fail(DG_ERR_ARG, "layer task: a weighted operator runs forward only, over a table that is not scaled yet");
   const dg_csr &c = transpose ? g->bwd : g->fwd;
   o.rowptr = c.rowptr; o.lhead = c.lhead; o.lds_split = c.lds_split; o.lds_blk_begin = 0; o.lds_blk_count = 0;
   o.dinv_gather = transpose ? g->dinv_dst : g->dinv_src;

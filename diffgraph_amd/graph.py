@@ -43,7 +43,7 @@ class CSRGraph:
                                         int(group_max), int(seg_len), C.byref(h))
         _lib.check(rc, "dg_graph_create_ex")
         self._h = h
-        self._n = int(num_nodes)
+        self._n = self._rows = int(num_nodes)
         self._nnz = int(src.size)
 
     # -- constructors mirroring the reference's DataHandler helpers --------------------
@@ -62,6 +62,28 @@ class CSRGraph:
         coo = mat.tocoo()
         return cls(coo.row, coo.col, coo.shape[0], **kw)
 
+    @classmethod
+    def weighted(cls, rows, cols, weights, n_rows: int, n_cols: int, group_max: int = 0, seg_len: int = 0,
+                 device=None) -> "CSRGraph":
+        """A rectangular operator with a weight per entry on the propagation kernels: a layer over it with slope 1
+        and no normalisation gives out[r] = sum_(r,c) weight * x[c] -- x of max(n_rows, n_cols) rows, out of n_rows.
+        Forward only.  (HGDM's backward uses one to add up the last propagation step of all its graphs.)"""
+        rows = np.ascontiguousarray(np.asarray(rows), dtype=np.int32)
+        cols = np.ascontiguousarray(np.asarray(cols), dtype=np.int32)
+        weights = np.ascontiguousarray(np.asarray(weights), dtype=np.float32)
+        if not (rows.shape == cols.shape == weights.shape) or rows.ndim != 1:
+            raise ValueError("rows, cols and weights must be 1-D arrays of equal length")
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        with _lib.device_guard(device):
+            rc = _lib.load().dg_graph_create_weighted(int(n_rows), int(n_cols), int(rows.size), rows.ctypes.data,
+                                                      cols.ctypes.data, weights.ctypes.data, int(group_max), int(seg_len),
+                                                      C.byref(h))
+        _lib.check(rc, "dg_graph_create_weighted")
+        self._h = h
+        self._n, self._rows, self._nnz = max(int(n_rows), int(n_cols)), int(n_rows), int(rows.size)
+        return self
+
     # -- the few DGLGraph attributes callers use --------------------------------------
     @property
     def handle(self) -> C.c_void_p:
@@ -71,6 +93,10 @@ class CSRGraph:
 
     def num_nodes(self) -> int:
         return self._n
+
+    def num_rows(self) -> int:
+        """Rows a layer over this graph computes and writes (= num_nodes() except for weighted operators)."""
+        return self._rows
 
     def num_edges(self) -> int:
         return self._nnz

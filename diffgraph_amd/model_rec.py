@@ -17,10 +17,12 @@ from contextlib import contextmanager
 from types import SimpleNamespace
 from typing import List, Optional
 
+import numpy as np
 import torch
 from torch import nn
 
 from . import ops
+from .graph import CSRGraph
 from ._lib import DG_ACC_REBUILD, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
 from .diffusion import Denoise, GaussianDiffusion, dropout_args, dropout_rate
 from .layers import DGLLayer
@@ -58,18 +60,27 @@ class _PropagateFn(torch.autograd.Function):
         w = [None] * len(graphs)
         for l in range(L, 0, -1):
             tasks = []
+            # the tables of the step before the last lie one after the other: the merged last step reads them as one
+            stack = torch.empty((len(graphs),) + tuple(ref.shape), dtype=ref.dtype, device=ref.device) if l == 1 else None
             for g, graph in enumerate(graphs):
-                out = torch.empty_like(ref)
+                out = stack[g] if l == 1 else torch.empty_like(ref)
                 tasks.append(ops.BwdTask(graph, w[g], saved[g][l - 1], d_sum[g], out,
                                          DG_BWD_SAVED_PRESCALED if l < L else 0, slope))
                 w[g] = out
             ops.gcn_layer_bwd_batched(tasks)
-        tasks = []
-        for g, graph in enumerate(graphs):
-            out = torch.empty_like(ref)
-            tasks.append(ops.BwdTask(graph, w[g], None, None, out, 0, slope))
-            w[g] = out
-        ops.gcn_layer_bwd_batched(tasks)
+        merged = model.merged_last_step()
+        if merged is not None:
+            # G0 = sum_g A_g^T dZ_g as ONE table from one launch (no per-graph tables to write and add up later)
+            g0 = torch.empty_like(ref)
+            ops.gcn_layer_batched([ops.LayerTask(merged, stack.view(-1, ref.shape[1]), g0, None, None, 0, 1.0)])
+            w = [g0]
+        else:
+            tasks = []
+            for g, graph in enumerate(graphs):
+                out = torch.empty_like(ref)
+                tasks.append(ops.BwdTask(graph, w[g], None, None, out, 0, slope))
+                w[g] = out
+            ops.gcn_layer_bwd_batched(tasks)
         # every graph's layer sum starts from e0 (Model.py:57,74): d e0 = sum_g (d_sum_g + G0_g)
         if getattr(model, "defer_embedding_grad", False):
             model.embedding_grad_parts = d_sum + w   # diffgraph_amd.optim.Adam adds them up inside its step
@@ -190,6 +201,34 @@ class HGDM(nn.Module):
         self._head_buf: Optional[torch.Tensor] = None
         self.side_join_deferred = False
         self.side_overlap = True       # False: side_work() stays on the current stream (one kernel at a time, e.g. to time them)
+        self.merge_last_step = True    # False: the backward's last propagation step runs graph by graph (see merged_last_step)
+        self._merged = None
+
+    def merged_last_step(self) -> Optional[CSRGraph]:
+        """The last step of the backward pass is linear: d e0 gets sum_g A_g^T dZ_g, with no activation or
+        normalisation between the graphs' terms.  Stacking the graphs' dZ tables and putting all their edges into one
+        operator [n, G n] -- entry (r, g n + c) = the norm of r in graph g, for every edge of graph g; dZ_g carries its
+        own side's norm already -- makes that one launch with one output table instead of G tables the optimizer adds
+        up.  Built at first use; None for graphs the gather kernel does not run (one side held in LDS, bitmap graphs,
+        directed graphs) and when switched off."""
+        if not self.merge_last_step:
+            return None
+        if self._merged is None:
+            graphs = [self.target_adj] + self.behavior_mats
+            n = self.n_user + self.n_item
+            self._merged = False
+            if all(g.is_symmetric and g.schedule()["lds_split"] == 0 and g.schedule()["dense_splits"] == 0 for g in graphs) \
+                    and len(graphs) * n * self.n_hid * 4 < 2 ** 32:
+                rows, cols, weights = [], [], []
+                for k, g in enumerate(graphs):
+                    rowptr, colidx = g.csr()
+                    r = np.repeat(np.arange(n, dtype=np.int32), np.diff(rowptr))
+                    rows.append(r)
+                    cols.append(colidx + np.int32(k * n))
+                    weights.append(g.norms()[0][r])
+                self._merged = CSRGraph.weighted(np.concatenate(rows), np.concatenate(cols), np.concatenate(weights), n,
+                                                 len(graphs) * n, device=self.embedding_table.device)
+        return self._merged or None
 
     # -- work beside the main stream --------------------------------------------------------------------
     # The propagation kernels wait on memory most of the time; short launches that do not depend on them (the

@@ -96,7 +96,7 @@ def prepare_gcn_layer_batched(tasks: Sequence[LayerTask]):
         for nm in ("e_out", "acc_in", "acc_out"):
             v = getattr(t, nm)
             if v is not None:
-                _table(v, nm, n)
+                _table(v, nm, t.graph.num_rows())
         if t.partial_out is not None:
             _table(t.partial_out, "partial_out", n - int(t.partial_from))
         if t.row_norm_out is not None:

@@ -63,8 +63,22 @@ int dg_graph_create_ex(int32_t n_nodes, int64_t n_edges, const int32_t *src_host
                        const int32_t *dst_host, const int32_t *out_deg_host,
                        const int32_t *in_deg_host, int32_t group_max, int32_t seg_len,
                        dg_graph **out);
+/* A rectangular operator with one fp32 weight per entry, run by the same schedule and kernels as a graph:
+ *     out[r] = sum over the entries (r, c) of weight * x[c],   r < n_rows, c < n_cols
+ * (weight * x[c] rounded before the sum, entries of a row in ascending c).  The handle counts max(n_rows, n_cols)
+ * nodes -- the row count of the table x a layer task gathers from -- of which rows [0, n_rows) are computed and
+ * written; its degree norms are 1.  It runs forward only (dg_gcn_layer_fwd / dg_spmm_norm_act_fwd without transpose,
+ * no DG_IN_PRESCALED); with slope 1 and no normalisation asked for, the layer epilogue is the identity.
+ * Used to add up, in one launch and one output table, the last step of the backward pass over all the graphs of a
+ * layer: d e0 = sum_g A_g^T dZ_g (the reference's autograd adds these per graph, DiffGraph-Rec/Model.py:57,74 feed
+ * the same table to every graph). */
+int dg_graph_create_weighted(int32_t n_rows, int32_t n_cols, int64_t n_entries, const int32_t *row_host,
+                             const int32_t *col_host, const float *weight_host, int32_t group_max,
+                             int32_t seg_len, dg_graph **out);
 void dg_graph_destroy(dg_graph *g);
 int32_t dg_graph_num_nodes(const dg_graph *g);
+/* rows a layer over this handle computes (= num_nodes except for weighted operators) */
+int32_t dg_graph_num_rows(const dg_graph *g);
 int64_t dg_graph_num_edges(const dg_graph *g);
 /* 1 if the edge set equals its transpose (then forward and backward share one CSR). */
 int dg_graph_is_symmetric(const dg_graph *g);

@@ -1217,3 +1217,52 @@ def test_dense_graphs_backward_matches_oracle_autograd():
     for o, want in zip(sums, (tgt, s1, s2)):
         assert_rows_close(o.detach(), want.detach(), what="dense nc forward")
     assert_rows_close(embed.grad, e_cpu.grad, rtol=1e-5, what="dense nc d embed")
+
+
+def test_weighted_operator_on_the_layer_kernels():
+    """CSRGraph.weighted: out[r] = sum of weight * x[c] over a rectangular operator with rows of every class (empty,
+    short, longer than a 16-lane group takes whole, cut into pieces), a repeated entry, and more columns than rows and
+    the other way round; the rows beyond n_rows are not written."""
+    from diffgraph_amd._lib import DG_IN_PRESCALED
+    rng = np.random.default_rng(12)
+    for n_rows, n_cols in ((300, 1500), (900, 200)):
+        deg = rng.integers(0, 40, n_rows)
+        deg[5], deg[6], deg[7] = 0, n_cols, 700 % n_cols + 100
+        rows = np.repeat(np.arange(n_rows), deg)
+        cols = np.concatenate([rng.choice(n_cols, d, replace=False) for d in deg])
+        rows, cols = np.append(rows, rows[:3]), np.append(cols, cols[:3])        # the same entry twice: both count
+        wts = rng.standard_normal(len(rows)).astype(np.float32)
+        op = dg.CSRGraph.weighted(rows, cols, wts, n_rows, n_cols)
+        assert (op.num_nodes(), op.num_rows(), op.num_edges()) == (max(n_rows, n_cols), n_rows, len(rows))
+        x = torch.from_numpy(rng.standard_normal((max(n_rows, n_cols), 64)).astype(np.float32))
+        out = torch.full((n_rows + 4, 64), 7.0, device=DEV)
+        ops.gcn_layer_batched([ops.LayerTask(op, dev(x), out[:n_rows], None, None, 0, 1.0)])
+        want = torch.zeros(n_rows, 64, dtype=torch.float64)
+        want.index_add_(0, T(rows.astype(np.int64)), x.double()[cols] * T(wts).double()[:, None])
+        assert_rows_close(out[:n_rows], want, what=f"weighted operator {n_rows}x{n_cols}")
+        assert bool((out[n_rows:] == 7.0).all())
+        with pytest.raises(dg.DiffGraphHipError):        # forward only, over an unscaled table
+            ops.gcn_layer_batched([ops.LayerTask(op, dev(x), out[:n_rows], None, None, DG_IN_PRESCALED, 1.0)])
+        with pytest.raises(dg.DiffGraphHipError):
+            ops.spmm_norm_act(op, dev(x), 1.0, transpose=True)
+
+
+def test_merged_last_backward_step_equals_the_per_graph_steps():
+    """HGDM's backward with the last propagation step of all graphs merged into one weighted operator against the
+    same backward graph by graph: the gradient of the embedding table agrees to rounding (the order of the sum over
+    the graphs differs), forward values are the same bits."""
+    wl = dgdata.rec_workload("tiny")
+    fx = tiny_fixture()[0]
+    grads = {}
+    for merge in (True, False):
+        m = rec_model(wl, fx)
+        m.set_embeddings(dev(fx["user_emb"]), dev(fx["item_emb"]))
+        m.merge_last_step = merge
+        gen = torch.Generator().manual_seed(3)
+        ru, ri = torch.randn(wl.n_user, 64, generator=gen), torch.randn(wl.n_item, 64, generator=gen)
+        tu, ti, hu, hi = m.forward()
+        ((tu * dev(ru)).sum() + (ti * dev(ri)).sum() + (hu * dev(ru)).sum() * 0.5 + (hi * dev(ri)).sum() * 0.25).backward()
+        grads[merge] = (m.embedding_table.grad.clone(), tu.detach().clone(), hi.detach().clone())
+        assert (m.merged_last_step() is not None) == merge
+    assert torch.equal(grads[True][1], grads[False][1]) and torch.equal(grads[True][2], grads[False][2])
+    assert_rows_close(grads[True][0], grads[False][0], rtol=2e-6, what="d e0, merged last step vs per graph")
