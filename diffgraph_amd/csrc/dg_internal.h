@@ -169,4 +169,5 @@ struct dg_task_dev {
 struct dg_task_batch {
   dg_task_dev t[DG_MAX_TASKS];
   int32_t n_tasks;
+  int32_t gather_blocks = 0;  // dense_rows_kernel: its first gather_blocks workgroups do gcn_layer_kernel's work (0: none)
 };

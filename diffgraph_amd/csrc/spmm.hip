@@ -562,12 +562,20 @@ constexpr int kDenseStage = 3 * kDensePlane;
 // row * dense_splits + range; hub_reduce_kernel adds a row's ranges in order and applies the epilogue.
 __global__ __launch_bounds__(64 * kDenseWaves) void dense_rows_kernel(const dg_task_batch batch) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[2 * kDenseStage];
+  if ((int)blockIdx.x < batch.gather_blocks) {
+    // the batch's sparse graphs: their few gather workgroups ride along instead of taking a launch of their own
+    const dg_task_dev &G = find_task(batch, blockIdx.x, false);
+    if (G.flags & DG_IN_PRESCALED) layer_block<false>(G, blockIdx.x - G.blk_begin);
+    else layer_block<true>(G, blockIdx.x - G.blk_begin);
+    return;
+  }
+  const int blk = (int)blockIdx.x - batch.gather_blocks;
   int ti = 0;
   for (int k = 0; k < batch.n_tasks; ++k)
-    if (batch.t[k].dense_splits > 0 && (int)blockIdx.x >= batch.t[k].dense_blk_begin) ti = k;
+    if (batch.t[k].dense_splits > 0 && blk >= batch.t[k].dense_blk_begin) ti = k;
   const dg_task_dev &T = batch.t[__builtin_amdgcn_readfirstlane(ti)];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
-  const int lb = blockIdx.x - T.dense_blk_begin;
+  const int lb = blk - T.dense_blk_begin;
   const int S = T.dense_splits, group = lb / S, split = lb - group * S;
   const int tile = group * kDenseWaves + wave;   // (the bitmap is allocated for whole tile groups: a missing tile reads zeros)
   const unsigned row_bytes = (unsigned)T.dense_chunks * 128u;      // one feature of one plane: 64 bf16 per chunk
@@ -853,9 +861,14 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     }
   }
   for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
+  // A batch of dense graphs with a little gather-path work beside them (DBLP: the 11 113-edge co-author graph next to
+  // two bitmap graphs): those workgroups go first in the dense launch rather than into a launch of their own.
+  constexpr int32_t kRideAlongBlocks = 1024;
+  batch.gather_blocks = (dense_blocks > 0 && blocks <= kRideAlongBlocks) ? blocks : 0;
   if (dense_blocks > 0) {
     hipLaunchKernelGGL(dense_split_kernel, dim3(dense_chunks_max, n_tasks), dim3(256), 0, stream, batch);
-    hipLaunchKernelGGL(dense_rows_kernel, dim3(dense_blocks), dim3(64 * kDenseWaves), 0, stream, batch);
+    hipLaunchKernelGGL(dense_rows_kernel, dim3(batch.gather_blocks + dense_blocks), dim3(64 * kDenseWaves), 0, stream, batch);
+    if (batch.gather_blocks > 0) blocks = 0;
   }
   if (lds_blocks > 0 && full_rows) {
     const size_t lds_bytes = (size_t)(lds_rows_max + 1) * DG_D * sizeof(float);
