@@ -237,7 +237,149 @@ __global__ __launch_bounds__(64) void nc_nll_bwd_kernel(const float *__restrict_
   if (t < n_cls) d_b[t] = db;
 }
 
+// The whole loss head of DiffGraph_NC's cal_loss over the batch rows only (Model.py:79-89), one workgroup; a 16-lane
+// group per batch entry b (entries b, b + 16, ... per group):
+//   e = target[a] + diff[a];  z = e . w^T + bias;  label = argmax(onehot[a]) (first maximum) or labels[b];
+//   nll = -mean_b log_softmax(z)[label] (fp32)   and   diff_loss = mean_b row_loss[a] (fp64).
+// Kept for the backward call: the entries' softmax and labels.
+__global__ __launch_bounds__(256) void nc_head_fwd_kernel(const f32x4 *__restrict__ target, const f32x4 *__restrict__ diff,
+                                                          const double *__restrict__ row_loss, const f32x4 *__restrict__ w,
+                                                          const float *__restrict__ bias, const int64_t *__restrict__ ancs,
+                                                          const float *__restrict__ onehot, const int64_t *__restrict__ labels,
+                                                          int n_batch, int64_t n, int n_cls, float *__restrict__ entries,
+                                                          int32_t *__restrict__ label_out, float *__restrict__ nll,
+                                                          double *__restrict__ diff_loss) {
+  __shared__ float red_f[16];
+  __shared__ double red_d[16];
+  const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+  float s = 0.f;
+  double sd = 0.0;
+  for (int b = grp; b < n_batch; b += 16) {
+    const int64_t a = ancs[b];
+    float *pe = entries + (size_t)b * n_cls;
+    int y = -1;
+    if ((uint64_t)a < (uint64_t)n) {
+      if (onehot) {
+        y = 0;
+        float best = onehot[a * n_cls];
+        for (int c = 1; c < n_cls; ++c) {
+          const float v = onehot[a * n_cls + c];
+          if (v > best) { best = v; y = c; }
+        }
+      } else {
+        const int64_t yy = labels[b];
+        y = (uint64_t)yy < (uint64_t)n_cls ? (int)yy : -1;
+      }
+    }
+    if (l == 0) label_out[b] = y;
+    if (y < 0) {   // not gathered through: both losses are NaN
+      if (l < n_cls) pe[l] = __builtin_nanf("");
+      s += __builtin_nanf("");
+      sd += (double)__builtin_nanf("");
+      continue;
+    }
+    const f32x4 v = target[a * 16 + l] + diff[a * 16 + l];
+    float z[kMaxClasses];
+    for (int c = 0; c < n_cls; ++c) {
+      const f32x4 wc = w[c * 16 + l];
+      float d = v.x * wc.x + v.y * wc.y + v.z * wc.z + v.w * wc.w;
+      d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
+      z[c] = d + bias[c];
+    }
+    float mx = z[0];
+    for (int c = 1; c < n_cls; ++c) mx = fmaxf(mx, z[c]);
+    float se = 0.f;
+    for (int c = 0; c < n_cls; ++c) se += expf(z[c] - mx);
+    const float lse = mx + logf(se);
+    float zy = 0.f;
+    for (int c = 0; c < n_cls; ++c) {
+      if (l == 0) pe[c] = expf(z[c] - lse);
+      if (c == y) zy = z[c];
+    }
+    s += -(zy - lse);
+    sd += row_loss[a];
+  }
+  if (l == 0) { red_f[grp] = s; red_d[grp] = sd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    double td = 0.0;
+    for (int g = 0; g < 16; ++g) { t += red_f[g]; td += red_d[g]; }
+    nll[0] = t / (float)n_batch;
+    diff_loss[0] = td / (double)n_batch;
+  }
+}
+
+// Backward of nc_head_fwd_kernel, one workgroup of 64 threads (thread = embedding column), batch entries in order:
+// d_e[a] += dl_b . W (the gradient of target AND of diff: they enter as a sum), d_w[c] += dl_b[c] e[a], d_b += dl_b
+// with dl_b = g_nll (softmax_b - onehot(label_b)) / n_batch, and d_row_loss[a] += g_diff / n_batch.  d_e and
+// d_row_loss arrive zeroed.
+__global__ __launch_bounds__(64) void nc_head_bwd_kernel(const float *__restrict__ target, const float *__restrict__ diff,
+                                                         const float *__restrict__ w, const int64_t *__restrict__ ancs,
+                                                         const int32_t *__restrict__ label_in, const float *__restrict__ entries,
+                                                         const float *__restrict__ g_nll, const double *__restrict__ g_diff,
+                                                         int n_batch, int n_cls, float *__restrict__ d_e,
+                                                         double *__restrict__ d_row_loss, float *__restrict__ d_w,
+                                                         float *__restrict__ d_b) {
+  const int t = threadIdx.x;
+  float wc[kMaxClasses], dw[kMaxClasses], db = 0.f;
+  for (int c = 0; c < kMaxClasses; ++c) {
+    wc[c] = c < n_cls ? w[c * DG_D + t] : 0.f;
+    dw[c] = 0.f;
+  }
+  const float scale = g_nll[0] / (float)n_batch;
+  const double dscale = g_diff[0] / (double)n_batch;
+  for (int b = 0; b < n_batch; ++b) {
+    const int y = label_in[b];
+    if (y < 0) continue;
+    const int64_t a = ancs[b];
+    const float ev = target[a * DG_D + t] + diff[a * DG_D + t];
+    float de = 0.f;
+    for (int c = 0; c < n_cls; ++c) {
+      const float dl = scale * (entries[(size_t)b * n_cls + c] - (c == y ? 1.f : 0.f));
+      de = fmaf(dl, wc[c], de);
+      dw[c] = fmaf(dl, ev, dw[c]);
+      if (t == c) db += dl;
+    }
+    d_e[a * DG_D + t] += de;   // entries in order, one thread per column: a row named twice is added twice, in order
+    if (t == 0) d_row_loss[a] += dscale;
+  }
+  for (int c = 0; c < n_cls; ++c) d_w[c * DG_D + t] = dw[c];
+  if (t < n_cls) d_b[t] = db;
+}
+
 }  // namespace
+
+extern "C" int dg_nc_head_fwd(const float *target, const float *diff, const double *row_loss, const float *w, const float *b,
+                              const int64_t *ancs, const float *onehot, const int64_t *labels, int32_t n_batch, int64_t n,
+                              int32_t d, int32_t n_cls, float *entries, int32_t *label_out, float *nll, double *diff_loss,
+                              void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_nc_head_fwd: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!target || !diff || !row_loss || !w || !b || !ancs || !entries || !label_out || !nll || !diff_loss)
+    return dg_fail(DG_ERR_ARG, "dg_nc_head_fwd: NULL argument");
+  if (!onehot && !labels) return dg_fail(DG_ERR_ARG, "dg_nc_head_fwd: neither a one-hot label table nor labels given");
+  if (n_batch <= 0 || n <= 0 || n_cls <= 0 || n_cls > kMaxClasses) return dg_fail(DG_ERR_ARG, "dg_nc_head_fwd: bad sizes");
+  if (((uintptr_t)target | (uintptr_t)diff | (uintptr_t)w) & 15) return dg_fail(DG_ERR_ARG, "dg_nc_head_fwd: tables must be 16-byte aligned");
+  hipLaunchKernelGGL(nc_head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4 *>(target),
+                     reinterpret_cast<const f32x4 *>(diff), row_loss, reinterpret_cast<const f32x4 *>(w), b, ancs, onehot, labels,
+                     n_batch, n, n_cls, entries, label_out, nll, diff_loss);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dg_nc_head_bwd(const float *target, const float *diff, const float *w, const int64_t *ancs,
+                              const int32_t *label_in, const float *entries, const float *g_nll, const double *g_diff,
+                              int32_t n_batch, int64_t n, int32_t d, int32_t n_cls, float *d_e, double *d_row_loss, float *d_w,
+                              float *d_b, void *stream) {
+  if (d != DG_D) return dg_fail(DG_ERR_DIM, "dg_nc_head_bwd: embedding width %d unsupported (built for %d)", d, DG_D);
+  if (!target || !diff || !w || !ancs || !label_in || !entries || !g_nll || !g_diff || !d_e || !d_row_loss || !d_w || !d_b)
+    return dg_fail(DG_ERR_ARG, "dg_nc_head_bwd: NULL argument");
+  if (n_batch <= 0 || n <= 0 || n_cls <= 0 || n_cls > kMaxClasses) return dg_fail(DG_ERR_ARG, "dg_nc_head_bwd: bad sizes");
+  hipLaunchKernelGGL(nc_head_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, target, diff, w, ancs, label_in, entries, g_nll,
+                     g_diff, n_batch, n_cls, d_e, d_row_loss, d_w, d_b);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int dg_linear_fwd(const float *x, const float *w, const float *bias, int32_t n, int32_t k, int32_t m, float *y,
                              void *stream) {

@@ -67,6 +67,28 @@ class _NLLHeadFn(torch.autograd.Function):
         return d_e, d_w, d_b, None, None
 
 
+class _LossHeadFn(torch.autograd.Function):
+    """Everything of cal_loss after training_losses2's rows (Model.py:80-89) as one differentiable op over the batch
+    rows: all_embeddings = target + diffused, dense, log_softmax, nll_loss against argmax(label[ancs]), and the batch
+    mean of the per-row diffusion losses.  Returns (nll fp32 scalar, diff_loss fp64 scalar)."""
+
+    @staticmethod
+    def forward(ctx, target, diffused, row_loss, w, b, ancs, label):
+        target, diffused, row_loss = target.contiguous(), diffused.contiguous(), row_loss.contiguous()
+        w, b = w.contiguous(), b.contiguous()
+        nll, diff_loss, entries, labels = ops.nc_head_fwd(target, diffused, row_loss, w, b, ancs, label)
+        ctx.save_for_backward(target, diffused, w, ancs, labels, entries)
+        return nll[0], diff_loss[0]
+
+    @staticmethod
+    def backward(ctx, g_nll, g_diff):
+        target, diffused, w, ancs, labels, entries = ctx.saved_tensors
+        g_nll = torch.zeros(1, dtype=torch.float32, device=w.device) if g_nll is None else g_nll.reshape(1).float().contiguous()
+        g_diff = torch.zeros(1, dtype=torch.float64, device=w.device) if g_diff is None else g_diff.reshape(1).double().contiguous()
+        d_e, d_row_loss, d_w, d_b = ops.nc_head_bwd(target, diffused, w, ancs, labels, entries, g_nll, g_diff)
+        return d_e, d_e, d_row_loss, d_w, d_b, None, None
+
+
 def _launch_distinct(tasks, launch) -> None:
     """Graphs that share a handle cannot share a launch (one hub slab per handle)."""
     seen, batch = set(), []
@@ -189,14 +211,15 @@ class HGDM(nn.Module):
         the range check of caller-supplied timesteps (a host synchronisation a recorded step cannot have)."""
         s1, s2, target_embedding = self.forward(he_adjs, initial_feature)
         source_embeddings = s1 + s2
-        diff_loss, diff_embeddings = self.diffusion_model.training_losses2(
-            self.user_denoise_model, target_embedding, source_embeddings, ancs, ts, noise, keep_mask, validate, drop_seed)
-        diff_loss = diff_loss.mean()
-        all_embeddings = target_embedding + diff_embeddings
+        # training_losses2 before its [batch] gather: the head below gathers the batch rows of everything at once
+        row_loss, diff_embeddings = self.diffusion_model.training_losses_rows(
+            self.user_denoise_model, target_embedding, source_embeddings, ts, noise, keep_mask, validate, drop_seed)
         ancs = ancs.long().contiguous()
-        batch_label = torch.argmax(label[ancs], dim=-1)
-        # log_softmax(dense(.))[ancs] + nll_loss in one op: only the batch rows' scores are ever used
-        return _NLLHeadFn.apply(all_embeddings, self.dense.weight, self.dense.bias, ancs, batch_label), diff_loss
+        if not (label.dtype == torch.float32 and label.dim() == 2 and label.is_contiguous()):
+            label = torch.argmax(label[ancs], dim=-1)        # (any other label table: the batch's labels by torch)
+        # all_embeddings = target + diffused, log_softmax(dense(.))[ancs], nll_loss and diff_loss[ancs].mean() in one op:
+        # only the batch rows' scores are ever used
+        return _LossHeadFn.apply(target_embedding, diff_embeddings, row_loss, self.dense.weight, self.dense.bias, ancs, label)
 
     def get_embeds(self, ancs, label, he_adjs, initial_feature):  # Model.py:90-99
         all_embeddings, _ = self.get_allembeds(he_adjs, initial_feature)

@@ -768,3 +768,54 @@ def nc_nll_bwd(e: torch.Tensor, w: torch.Tensor, ancs, labels, entries, g: torch
                                    d_b.data_ptr(), _lib.stream_ptr(e.device))
     _lib.check(rc, "dg_nc_nll_bwd")
     return d_e, d_w, d_b
+
+
+def nc_head_fwd(target: torch.Tensor, diff: torch.Tensor, row_loss: torch.Tensor, w: torch.Tensor, b: torch.Tensor,
+                ancs: torch.Tensor, label: torch.Tensor):
+    """The loss head of DiffGraph_NC's cal_loss over the batch rows (Model.py:79-89): nll_loss(log_softmax(dense(target +
+    diff))[ancs], labels) and mean(row_loss[ancs]).  `label`: the one-hot table [n, n_cls] (float32; argmax inside) or
+    the batch's labels (int64 [B]).  Returns (nll fp32[1], diff_loss fp64[1], entries, labels int32[B])."""
+    _table(target, "target embeddings")
+    n = target.shape[0]
+    _table(diff, "denoised embeddings", n)
+    _vec(row_loss, "row losses", torch.float64, n)
+    _mat(w, "dense weight", None, DG_D)
+    n_cls = w.shape[0]
+    _vec(b, "dense bias", torch.float32, n_cls)
+    B = ancs.numel()
+    _index_vec(ancs, "ancs", B)
+    onehot = labels = None
+    if label.dtype == torch.int64:
+        _index_vec(label, "labels", B)
+        labels = label
+    else:
+        _mat(label, "one-hot labels", n, n_cls)
+        onehot = label
+    dev = target.device
+    entries = torch.empty((B, n_cls), dtype=torch.float32, device=dev)
+    label_out = torch.empty(B, dtype=torch.int32, device=dev)
+    nll = torch.empty(1, dtype=torch.float32, device=dev)
+    diff_loss = torch.empty(1, dtype=torch.float64, device=dev)
+    rc = _lib.load().dg_nc_head_fwd(target.data_ptr(), diff.data_ptr(), row_loss.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                    ancs.data_ptr(), _ptr(onehot), _ptr(labels), B, n, DG_D, n_cls, entries.data_ptr(),
+                                    label_out.data_ptr(), nll.data_ptr(), diff_loss.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_nc_head_fwd")
+    return nll, diff_loss, entries, label_out
+
+
+def nc_head_bwd(target, diff, w, ancs, label_out, entries, g_nll: torch.Tensor, g_diff: torch.Tensor):
+    """Backward of nc_head_fwd.  Returns (d_e -- the gradient of target and of diff alike --, d_row_loss fp64[n], d_w, d_b)."""
+    n, n_cls, dev = target.shape[0], w.shape[0], target.device
+    _vec(g_nll, "upstream gradient of nll", torch.float32, 1)
+    _vec(g_diff, "upstream gradient of diff_loss", torch.float64, 1)
+    # one cleared buffer for both tables that arrive zeroed: [n, 64] fp32, then [n] fp64
+    buf = torch.zeros(n * DG_D + 2 * n, dtype=torch.float32, device=dev)
+    d_e = buf[: n * DG_D].view(n, DG_D)
+    d_row_loss = buf[n * DG_D:].view(torch.float64)
+    d_w = torch.empty_like(w)
+    d_b = torch.empty(n_cls, dtype=torch.float32, device=dev)
+    rc = _lib.load().dg_nc_head_bwd(target.data_ptr(), diff.data_ptr(), w.data_ptr(), ancs.data_ptr(), label_out.data_ptr(),
+                                    entries.data_ptr(), g_nll.data_ptr(), g_diff.data_ptr(), ancs.numel(), n, DG_D, n_cls,
+                                    d_e.data_ptr(), d_row_loss.data_ptr(), d_w.data_ptr(), d_b.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_nc_head_bwd")
+    return d_e, d_row_loss, d_w, d_b

@@ -475,6 +475,22 @@ int dg_nc_nll_fwd(const float *logits, const int64_t *ancs, const int64_t *label
 int dg_nc_nll_bwd(const float *e, const float *w, const int64_t *ancs, const int64_t *labels, const float *entries,
                   const float *g, int32_t n_batch, int64_t n, int32_t d, int32_t n_cls, float *d_e, float *d_w,
                   float *d_b, void *stream);
+/* The loss head of DiffGraph_NC's cal_loss over the batch rows only, in one launch each way (Model.py:79-89):
+ *     e = target[a] + diff[a]  (all_embeddings, :83);  nll[0] = F.nll_loss(F.log_softmax(dense(e)), label)  (fp32);
+ *     diff_loss[0] = mean_b row_loss[a_b]  (fp64: training_losses2's per-row loss gathered by the batch and averaged, :80-82)
+ * label_b = argmax(onehot[a_b]) (DEVICE float[n][n_cls], first maximum, :86) or, with onehot NULL, labels[b].
+ * entries (DEVICE float[n_batch][n_cls]) and label_out (DEVICE int32[n_batch], -1 = index out of range: both losses
+ * NaN, the entry not gathered through) are kept for dg_nc_head_bwd, which ADDS the batch rows' gradients into
+ * d_e[n][64] (= the gradient of target and of diff alike) and d_row_loss[n] (fp64) -- both zeroed by the caller,
+ * entries in batch order -- and writes d_w / d_b of the dense layer; g_nll / g_diff: DEVICE float[1] / double[1]. */
+int dg_nc_head_fwd(const float *target, const float *diff, const double *row_loss, const float *w, const float *b,
+                   const int64_t *ancs, const float *onehot, const int64_t *labels, int32_t n_batch, int64_t n,
+                   int32_t d, int32_t n_cls, float *entries, int32_t *label_out, float *nll, double *diff_loss,
+                   void *stream);
+int dg_nc_head_bwd(const float *target, const float *diff, const float *w, const int64_t *ancs,
+                   const int32_t *label_in, const float *entries, const float *g_nll, const double *g_diff,
+                   int32_t n_batch, int64_t n, int32_t d, int32_t n_cls, float *d_e, double *d_row_loss, float *d_w,
+                   float *d_b, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Adam step of one table, the gradient given as the n_parts (<= 16) tables whose left-to-right sum

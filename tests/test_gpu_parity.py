@@ -485,6 +485,50 @@ def test_nc_classification_head_matches_torch():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("labels_as", ["onehot", "indices"])
+def test_nc_loss_head_matches_torch(labels_as):
+    """Everything of DiffGraph_NC's cal_loss after the per-row diffusion losses (Model.py:80-89) as one op against
+    torch's: target + diffused, dense, log_softmax, the batch rows, nll_loss against argmax(label[ancs]), and
+    diff_loss[ancs].mean() in fp64 -- values and all five gradients, with a batch that names a row three times; an
+    index out of range gives NaN losses and no gather."""
+    import torch.nn.functional as F
+    from diffgraph_amd.model_nc import _LossHeadFn
+    gen = torch.Generator().manual_seed(6)
+    n, n_cls, B = 500, 4, 37
+    tgt, dif = torch.randn(n, 64, generator=gen), torch.randn(n, 64, generator=gen) * 0.1
+    rl = torch.rand(n, generator=gen, dtype=torch.float64)
+    w, b = torch.randn(n_cls, 64, generator=gen) * 0.3, torch.randn(n_cls, generator=gen)
+    ancs = torch.randint(0, n, (B,), generator=gen)
+    ancs[5] = ancs[2]
+    ancs[30] = ancs[2]
+    onehot = torch.zeros(n, n_cls)
+    onehot[torch.arange(n), torch.randint(0, n_cls, (n,), generator=gen)] = 1.0
+    onehot[int(ancs[7])] = 0.0                  # no class marked: argmax takes the first, as torch does
+    label = dev(onehot) if labels_as == "onehot" else dev(torch.argmax(onehot[ancs], dim=-1))
+    td, dd, rd, wd, bd = (dev(t).requires_grad_(True) for t in (tgt, dif, rl, w, b))
+    nll, diff = _LossHeadFn.apply(td, dd, rd, wd, bd, dev(ancs), label)
+    assert nll.dtype == torch.float32 and diff.dtype == torch.float64
+    (nll * 1.7 + diff * 0.6).backward()
+    t6, d6, r6, w6, b6 = (t.double().requires_grad_(True) for t in (tgt, dif, rl, w, b))
+    want_nll = F.nll_loss(F.log_softmax((t6 + d6) @ w6.t() + b6, dim=1)[ancs], torch.argmax(onehot[ancs], dim=-1))
+    want_diff = r6[ancs].mean()
+    (want_nll * 1.7 + want_diff * 0.6).backward()
+    assert float(nll.detach()) == pytest.approx(float(want_nll.detach()), rel=1e-5)
+    assert float(diff.detach()) == pytest.approx(float(want_diff.detach()), rel=1e-14)
+    assert_rows_close(td.grad, t6.grad, what="nc loss head d target")
+    assert torch.equal(td.grad, dd.grad)
+    np.testing.assert_allclose(rd.grad.cpu().numpy(), r6.grad.numpy(), rtol=1e-14, atol=0)
+    assert_close_to_max(wd.grad, w6.grad, 1e-5, "nc loss head d weight")
+    assert_close_to_max(bd.grad, b6.grad, 1e-5, "nc loss head d bias")
+    bad = ancs.clone()
+    bad[3] = n
+    td2 = dev(tgt).requires_grad_(True)
+    nll_bad, diff_bad = _LossHeadFn.apply(td2, dev(dif), dev(rl), dev(w), dev(b), dev(bad), label)
+    assert torch.isnan(nll_bad) and torch.isnan(diff_bad)
+    (nll_bad + diff_bad).backward()
+    torch.cuda.synchronize()
+
+
 def test_adam_matches_torch_adam_over_steps():
     """diffgraph_amd.optim.Adam (table kernel fed with the backward pass's gradient parts + torch's Adam for the
     denoisers) against torch.optim.Adam on an identical model (DiffGraph-Rec/main.py:117-119), five steps."""
