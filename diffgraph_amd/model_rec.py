@@ -202,7 +202,7 @@ class HGDM(nn.Module):
         self.side_join_deferred = False
         self.side_overlap = True       # False: side_work() stays on the current stream (one kernel at a time, e.g. to time them)
         self.merge_last_step = True    # False: the backward's last propagation step runs graph by graph (see merged_last_step)
-        self._merged = None
+        self._merged, self._merged_key = None, None
 
     def merged_last_step(self) -> Optional[CSRGraph]:
         """The last step of the backward pass is linear: d e0 gets sum_g A_g^T dZ_g, with no activation or
@@ -213,10 +213,11 @@ class HGDM(nn.Module):
         directed graphs) and when switched off."""
         if not self.merge_last_step:
             return None
-        if self._merged is None:
-            graphs = [self.target_adj] + self.behavior_mats
+        graphs = [self.target_adj] + self.behavior_mats
+        key = tuple(id(g) for g in graphs)
+        if self._merged is None or self._merged_key != key:      # (graphs swapped since: build it anew)
             n = self.n_user + self.n_item
-            self._merged = False
+            self._merged, self._merged_key = False, key
             if all(g.is_symmetric and g.schedule()["lds_split"] == 0 and g.schedule()["dense_splits"] == 0 for g in graphs) \
                     and len(graphs) * n * self.n_hid * 4 < 2 ** 32:
                 rows, cols, weights = [], [], []
