@@ -244,9 +244,9 @@ def bench_nc_train(steps: int, warmup: int, cpu_baseline: bool, use_graph: bool 
     onehot[torch.arange(NA, device=dev), labels.to(dev)] = 1.0
     gen = torch.Generator().manual_seed(1)
     ancs = torch.sort(torch.randperm(NA, generator=gen)[: model.args.batch])[0].to(dev)
-    # capturable: Adam's step counter lives on the device, so the whole step can be recorded as one HIP graph;
-    # fused: one multi-tensor launch for the ten parameter tensors instead of ~35 small ones
-    opt = torch.optim.Adam(model.parameters(), lr=3e-3, weight_decay=0, capturable=True, fused=True)
+    # one launch for the ten parameter tensors, Adam's step count on the device: the whole step can be recorded
+    from diffgraph_amd.optim import SmallAdam
+    opt = SmallAdam(model.parameters(), lr=3e-3, weight_decay=0)
 
     def step():
         nll, diff = model.cal_loss(ancs, onehot, adjs, fd)

@@ -157,6 +157,8 @@ SIGNATURES = {
     "dg_nc_head_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5),
     "dg_nc_head_bwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 5),
     "dg_adam_prepare": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+    "dg_adam_multi": (C.c_int, [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_int64), C.c_int32, C.c_void_p] + [C.c_float] * 5
+                      + [C.c_void_p]),
     "dg_rec_head_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 10),
 }
 

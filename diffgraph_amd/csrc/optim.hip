@@ -12,6 +12,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -58,7 +60,75 @@ __global__ __launch_bounds__(256) void adam_table_kernel(const adam_args a) {
   }
 }
 
+// Up to kMaxTensors small parameter tensors in ONE launch (the denoiser / dense-layer weights: a few thousand
+// elements each).  blockIdx.y names the tensor.  Every workgroup derives the step count t = state[0] + 1 and the
+// bias corrections itself; the workgroup that finishes last (a counter in state[3]) writes t back and clears the
+// counter, so that a recorded launch advances the count on every replay without a launch of its own.
+constexpr int kMaxTensors = 32;
+
+struct adam_multi_args {
+  float *param[kMaxTensors];
+  const float *grad[kMaxTensors];
+  float *exp_avg[kMaxTensors], *exp_avg_sq[kMaxTensors];
+  int32_t count[kMaxTensors];
+  float *state;
+  float lr, beta1, beta2, eps, weight_decay;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const adam_multi_args a) {
+  const float t = a.state[0] + 1.0f;
+  const float bc1 = 1.0f - powf(a.beta1, t), bc2_sqrt = sqrtf(1.0f - powf(a.beta2, t));
+  const float step_size = a.lr / bc1;
+  const int k = blockIdx.y;
+  float *p = a.param[k], *m = a.exp_avg[k], *v = a.exp_avg_sq[k];
+  const float *g = a.grad[k];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.count[k]; i += gridDim.x * 256) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (a.weight_decay != 0.f) gi += pi * a.weight_decay;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - a.beta1);
+    const float vi = v[i] * a.beta2 + gi * gi * (1.0f - a.beta2);
+    p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + a.eps));
+    m[i] = mi;
+    v[i] = vi;
+  }
+  // all reads of state[0] are done once every workgroup has passed this point
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned *done = reinterpret_cast<unsigned *>(a.state + 3);
+    __threadfence();
+    if (atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1) {
+      __atomic_store_n(done, 0u, __ATOMIC_RELAXED);
+      a.state[0] = t;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int dg_adam_multi(float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                             float *const *exp_avg_sq_host, const int64_t *counts_host, int32_t n_tensors, float *state,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, void *stream) {
+  if (!params_host || !grads_host || !exp_avg_host || !exp_avg_sq_host || !counts_host || !state)
+    return dg_fail(DG_ERR_ARG, "dg_adam_multi: NULL argument");
+  if (n_tensors < 1 || n_tensors > kMaxTensors) return dg_fail(DG_ERR_ARG, "dg_adam_multi: n_tensors must be in [1,%d]", kMaxTensors);
+  adam_multi_args a;
+  int64_t longest = 0;
+  for (int k = 0; k < kMaxTensors; ++k) {
+    const int j = k < n_tensors ? k : 0;
+    if (!params_host[j] || !grads_host[j] || !exp_avg_host[j] || !exp_avg_sq_host[j])
+      return dg_fail(DG_ERR_ARG, "dg_adam_multi: tensor %d: NULL pointer", j);
+    if (counts_host[j] < 0 || counts_host[j] > INT32_MAX) return dg_fail(DG_ERR_SIZE, "dg_adam_multi: tensor %d: bad element count", j);
+    a.param[k] = params_host[j]; a.grad[k] = grads_host[j]; a.exp_avg[k] = exp_avg_host[j]; a.exp_avg_sq[k] = exp_avg_sq_host[j];
+    a.count[k] = (int32_t)counts_host[j];
+    longest = std::max(longest, counts_host[j]);
+  }
+  a.state = state; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+  const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((longest + 255) / 256, 1), 64);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, a);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int dg_adam_prepare(float *state, float beta1, float beta2, void *stream) {
   if (!state) return dg_fail(DG_ERR_ARG, "dg_adam_prepare: NULL argument");

@@ -73,3 +73,53 @@ class Adam:
         self.rest.load_state_dict(sd["rest"])
         h = sd["hyper"]
         self.lr, self.betas, self.eps, self.weight_decay = h["lr"], tuple(h["betas"]), h["eps"], h["weight_decay"]
+
+
+class SmallAdam:
+    """torch.optim.Adam(params, lr, weight_decay=0) (DiffGraph_NC/main.py:356-357) for a handful of small parameter
+    tensors: ONE launch per step for all of them (`dg_adam_multi`), the step count on the device, so a recorded
+    training step can be replayed.  Parameters without a gradient are left alone, as torch does."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("no parameters")
+        if any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in self.params):
+            raise _lib.DiffGraphHipError("SmallAdam: parameters must be contiguous float32 GPU tensors")
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.state = torch.zeros(4, dtype=torch.float32, device=self.params[0].device)
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def step(self) -> None:
+        live = [(p, p.grad.contiguous(), m, v) for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq) if p.grad is not None]
+        n = len(live)
+        if n == 0:
+            return
+        if n > 32:
+            raise _lib.DiffGraphHipError("SmallAdam: at most 32 tensors per step (one launch, one step count)")
+        arrs = [(C.c_void_p * n)(*[t[k].data_ptr() for t in live]) for k in range(4)]
+        counts = (C.c_int64 * n)(*[t[0].numel() for t in live])
+        rc = _lib.load().dg_adam_multi(arrs[0], arrs[1], arrs[2], arrs[3], counts, n, self.state.data_ptr(), self.lr,
+                                       self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                       _lib.stream_ptr(self.state.device))
+        _lib.check(rc, "dg_adam_multi")
+
+    def state_dict(self) -> Dict:
+        return {"exp_avg": list(self.exp_avg), "exp_avg_sq": list(self.exp_avg_sq), "state": self.state,
+                "hyper": {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        with torch.no_grad():
+            for dst, src in zip(self.exp_avg + self.exp_avg_sq, list(sd["exp_avg"]) + list(sd["exp_avg_sq"])):
+                dst.copy_(src)
+            self.state.copy_(sd["state"])
+        h = sd["hyper"]
+        self.lr, self.betas, self.eps, self.weight_decay = h["lr"], tuple(h["betas"]), h["eps"], h["weight_decay"]

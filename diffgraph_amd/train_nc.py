@@ -2,8 +2,8 @@
 the HIP path.
 
 What differs from the reference's loop, and why the results do not:
-* a step (cal_loss, backward, Adam; main.py:378-387) is recorded once per batch size as a HIP graph and replayed: two
-  recordings, the full batch and the epoch's short last one.  The step's random inputs (timesteps, noise, the key of
+* a step (cal_loss, backward, Adam -- all ten parameter tensors in one launch; main.py:378-387) is recorded once per
+  batch size as a HIP graph and replayed: two recordings, the full batch and the epoch's short last one.  The step's random inputs (timesteps, noise, the key of
   the dropout mask) are drawn BEFORE the step into fixed device buffers, from a generator of the coach's own, so a
   replayed and an eagerly launched run with the same seed train on the same numbers;
 * the reference reads two losses back per step (`.item()`, main.py:381-383); here they are added up on the device and
@@ -23,6 +23,7 @@ import torch
 
 from . import io
 from .model_nc import DEFAULT_ARGS, HGDM
+from .optim import SmallAdam
 
 
 def f1_scores(y_true: torch.Tensor, y_pred: torch.Tensor, n_classes: int) -> Tuple[float, float]:
@@ -72,8 +73,8 @@ class NCCoach:
         self.label = h.labels.to(dev)
         self.nbclasses = int(self.label.shape[1])
         self.model = HGDM(int(self.initial_feature.shape[1]), self.args, device=dev)      # stays in train(): main.py never calls eval()
-        # capturable: the step counter lives on the device; fused: one launch for all parameter tensors
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=self.lr, weight_decay=0, capturable=True, fused=True)
+        # one launch for all parameter tensors, the step count on the device (a recorded step advances it per replay)
+        self.opt = SmallAdam(self.model.parameters(), lr=self.lr, weight_decay=0)
         n, B = int(self.initial_feature.shape[0]), int(self.args.batch)
         self._ancs = torch.zeros(B, dtype=torch.int64, device=dev)
         self._ts = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -100,9 +101,8 @@ class NCCoach:
         """Records one step over `size` authors.  The warm-up steps torch asks for before a capture are real steps on
         the draws already in the buffers; their effect on the model, Adam and the loss sums is undone afterwards (in
         place: the recording holds these tensors' addresses)."""
-        params = [p.detach().clone() for p in self.model.parameters()]
-        state = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.opt.state.items()}
-        sums = self._sums.clone()
+        o = self.opt
+        held = [t.detach().clone() for t in list(self.model.parameters()) + o.exp_avg + o.exp_avg_sq + [o.state, self._sums]]
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -113,13 +113,8 @@ class NCCoach:
         with torch.cuda.graph(graph):
             self._step(size)
         with torch.no_grad():
-            for p, q in zip(self.model.parameters(), params):
-                p.copy_(q)
-            for p, st in self.opt.state.items():      # moments and step counts the warm-up created start from zero
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        v.copy_(state[p][k]) if p in state else v.zero_()
-            self._sums.copy_(sums)
+            for t, q in zip(list(self.model.parameters()) + o.exp_avg + o.exp_avg_sq + [o.state, self._sums], held):
+                t.copy_(q)
         self._graphs[(size, self.model.training)] = graph
         return graph
 

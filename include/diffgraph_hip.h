@@ -510,6 +510,14 @@ int dg_adam_step_prepared(float *param, const float *const *grad_parts_host, int
                           float *exp_avg_sq, float *state, int64_t n_elems, float lr, float beta1, float beta2,
                           float eps, float weight_decay, void *stream);
 
+/* torch.optim.Adam.step() (same reference lines; amsgrad off) for n_tensors (<= 32) small parameter tensors in one
+ * launch: HOST arrays of DEVICE pointers (parameter, its gradient, its two moments) and of element counts.  state:
+ * DEVICE float[4], zero before the first step: word 0 the steps taken so far, advanced by the launch itself (a
+ * recorded launch steps on every replay), word 3 a counter the launch uses and leaves at zero. */
+int dg_adam_multi(float *const *params_host, const float *const *grads_host, float *const *exp_avg_host,
+                  float *const *exp_avg_sq_host, const int64_t *counts_host, int32_t n_tensors, float *state,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * All-rank evaluation.  Replaces the per-batch body of Coach.testEpoch
  * (DiffGraph-Rec/main.py:153-160) with the dense train-mask rows of AllRankTestData

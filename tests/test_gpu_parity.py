@@ -529,6 +529,28 @@ def test_nc_loss_head_matches_torch(labels_as):
     torch.cuda.synchronize()
 
 
+def test_small_adam_matches_torch_adam_over_steps():
+    """optim.SmallAdam (one launch for all tensors, step count on the device) against torch.optim.Adam: five steps over
+    tensors of odd sizes, one of them without a gradient (left alone), with and without weight decay."""
+    gen = torch.Generator().manual_seed(2)
+    shapes = [(64, 72), (64,), (4, 64), (4,), (334, 64), (1,), (7, 3)]
+    for wd in (0.0, 0.01):
+        mine = [dev(torch.randn(*sh, generator=torch.Generator().manual_seed(k))).requires_grad_(True) for k, sh in enumerate(shapes)]
+        ref = [p.detach().clone().double().requires_grad_(True) for p in mine]
+        a = dg.optim.SmallAdam(mine, lr=3e-3, weight_decay=wd)
+        b = torch.optim.Adam(ref, lr=3e-3, weight_decay=wd)
+        for step in range(5):
+            for k, (p, q) in enumerate(zip(mine, ref)):
+                g = torch.randn(*p.shape, generator=gen) * (10.0 ** (k - 3))
+                p.grad, q.grad = (None, None) if k == 5 else (dev(g), dev(g).double())
+            a.step()
+            b.step()
+        assert a.state.tolist() == [5.0, 0.0, 0.0, 0.0]
+        for k, (p, q) in enumerate(zip(mine, ref)):
+            assert_close_to_max(p.detach().reshape(1, -1), q.detach().reshape(1, -1), 1e-6, f"SmallAdam tensor {k} wd {wd}")
+        assert torch.equal(mine[5].detach(), dev(torch.randn(1, generator=torch.Generator().manual_seed(5))))
+
+
 def test_adam_matches_torch_adam_over_steps():
     """diffgraph_amd.optim.Adam (table kernel fed with the backward pass's gradient parts + torch's Adam for the
     denoisers) against torch.optim.Adam on an identical model (DiffGraph-Rec/main.py:117-119), five steps."""
