@@ -20,6 +20,7 @@ DG_BWD_SAVED_PRESCALED = 8
 DG_ACC_REBUILD = 16
 DG_BWD_NORM_FEED = 32
 DG_ROWS_PARTIAL_ONLY, DG_ROWS_FULL_ONLY = 64, 128
+DG_OUT_PLANES, DG_IN_PLANES = 0x200, 0x400
 
 
 class DiffGraphHipError(RuntimeError):

@@ -162,6 +162,8 @@ struct dg_task_dev {
   float *dense_x;
   int32_t dense_splits, dense_chunks, dense_cps, dense_tiles;
   int32_t dense_blk_begin;      // first block of this task in the dense_rows_kernel launch
+  int32_t red_blk_begin;        // first block of this task in the dense_reduce_kernel launch
+  int32_t red_parts;            // slab rows per row that kernel adds up (0: none, the row-wise backward step)
   int32_t blk_begin;      // first block of this task in the main launch
   int32_t hub_blk_begin;  // first block of this task in the hub-row reduce launch
 };

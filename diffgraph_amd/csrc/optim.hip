@@ -61,16 +61,18 @@ __global__ __launch_bounds__(256) void adam_table_kernel(const adam_args a) {
 }
 
 // Up to kMaxTensors small parameter tensors in ONE launch (the denoiser / dense-layer weights: a few thousand
-// elements each).  blockIdx.y names the tensor.  Every workgroup derives the step count t = state[0] + 1 and the
-// bias corrections itself; the workgroup that finishes last (a counter in state[3]) writes t back and clears the
-// counter, so that a recorded launch advances the count on every replay without a launch of its own.
-constexpr int kMaxTensors = 32;
+// elements each).  A workgroup takes kAdamPerBlock consecutive elements of one tensor (blk_begin: the tensors' first
+// workgroups).  Every workgroup derives the step count t = state[0] + 1 and the bias corrections itself; the
+// workgroup that finishes last (a counter in state[3]) writes t back and clears the counter, so that a recorded
+// launch advances the count on every replay without a launch of its own.
+constexpr int kMaxTensors = 32, kAdamPerBlock = 1024;
 
 struct adam_multi_args {
   float *param[kMaxTensors];
   const float *grad[kMaxTensors];
   float *exp_avg[kMaxTensors], *exp_avg_sq[kMaxTensors];
-  int32_t count[kMaxTensors];
+  int32_t count[kMaxTensors], blk_begin[kMaxTensors];
+  int32_t n_tensors;
   float *state;
   float lr, beta1, beta2, eps, weight_decay;
 };
@@ -79,10 +81,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const adam_multi_args a
   const float t = a.state[0] + 1.0f;
   const float bc1 = 1.0f - powf(a.beta1, t), bc2_sqrt = sqrtf(1.0f - powf(a.beta2, t));
   const float step_size = a.lr / bc1;
-  const int k = blockIdx.y;
+  int k = 0;
+  for (int j = 1; j < a.n_tensors; ++j)
+    if ((int)blockIdx.x >= a.blk_begin[j]) k = j;
   float *p = a.param[k], *m = a.exp_avg[k], *v = a.exp_avg_sq[k];
   const float *g = a.grad[k];
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.count[k]; i += gridDim.x * 256) {
+  const int base = ((int)blockIdx.x - a.blk_begin[k]) * kAdamPerBlock, end = min(a.count[k], base + kAdamPerBlock);
+  for (int i = base + threadIdx.x; i < end; i += 256) {
     float gi = g[i];
     const float pi = p[i];
     if (a.weight_decay != 0.f) gi += pi * a.weight_decay;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const adam_multi_args a
   if (threadIdx.x == 0) {
     unsigned *done = reinterpret_cast<unsigned *>(a.state + 3);
     __threadfence();
-    if (atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1) {
+    if (atomicAdd(done, 1u) == gridDim.x - 1) {
       __atomic_store_n(done, 0u, __ATOMIC_RELAXED);
       a.state[0] = t;
     }
@@ -113,19 +118,22 @@ extern "C" int dg_adam_multi(float *const *params_host, const float *const *grad
     return dg_fail(DG_ERR_ARG, "dg_adam_multi: NULL argument");
   if (n_tensors < 1 || n_tensors > kMaxTensors) return dg_fail(DG_ERR_ARG, "dg_adam_multi: n_tensors must be in [1,%d]", kMaxTensors);
   adam_multi_args a;
-  int64_t longest = 0;
+  int64_t blocks = 0;
   for (int k = 0; k < kMaxTensors; ++k) {
     const int j = k < n_tensors ? k : 0;
     if (!params_host[j] || !grads_host[j] || !exp_avg_host[j] || !exp_avg_sq_host[j])
       return dg_fail(DG_ERR_ARG, "dg_adam_multi: tensor %d: NULL pointer", j);
-    if (counts_host[j] < 0 || counts_host[j] > INT32_MAX) return dg_fail(DG_ERR_SIZE, "dg_adam_multi: tensor %d: bad element count", j);
+    if (counts_host[j] < 0 || counts_host[j] > (int64_t)1 << 28) return dg_fail(DG_ERR_SIZE, "dg_adam_multi: tensor %d: bad element count", j);
     a.param[k] = params_host[j]; a.grad[k] = grads_host[j]; a.exp_avg[k] = exp_avg_host[j]; a.exp_avg_sq[k] = exp_avg_sq_host[j];
     a.count[k] = (int32_t)counts_host[j];
-    longest = std::max(longest, counts_host[j]);
+    a.blk_begin[k] = (int32_t)blocks;
+    if (k < n_tensors) blocks += (counts_host[j] + kAdamPerBlock - 1) / kAdamPerBlock;
   }
+  if (blocks == 0) blocks = 1;   // (nothing but the step count to advance)
+  if (blocks > (1 << 20)) return dg_fail(DG_ERR_SIZE, "dg_adam_multi: these tensors are not small (use dg_adam_step for tables)");
+  a.n_tensors = n_tensors;
   a.state = state; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-  const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((longest + 255) / 256, 1), 64);
-  hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   DG_HIP(hipGetLastError());
   return 0;
 }

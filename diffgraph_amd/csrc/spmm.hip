@@ -168,12 +168,15 @@ __device__ __forceinline__ row_ctx load_row_ctx(const dg_task_dev &T, int row, i
 }
 
 // Backward of LeakyReLU + F.normalize + layer sum for one row (see dg_gcn_layer_bwd).
-__device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, const row_ctx &rc, f32x4 acc, int l) {
+// (`next_in`, when given, receives what was stored for the next gather to read.)
+__device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, const row_ctx &rc, f32x4 acc, int l,
+                                             f32x4 *next_in = nullptr) {
   const size_t o = (size_t)row * (DG_D / 4) + l;
   const float di = bcast16f<0>(rc.sc), dsrc = bcast16f<1>(rc.sc), rn = bcast16f<2>(rc.sc);
   f32x4 G = acc * di;
   if (!T.e_saved) {
     store_stream(T.e_out, o, G);
+    if (next_in) *next_in = G;
     return;
   }
   const f32x4 e = rc.a_in, g = rc.g_in;
@@ -198,12 +201,15 @@ __device__ __forceinline__ void epilogue_bwd(const dg_task_dev &T, int row, cons
   dz.y = e.y > 0.f ? dE.y : dE.y * slope;
   dz.z = e.z > 0.f ? dE.z : dE.z * slope;
   dz.w = e.w > 0.f ? dE.w : dE.w * slope;
-  store_stream(T.e_out, o, dz * dsrc);
+  dz *= dsrc;
+  store_stream(T.e_out, o, dz);
+  if (next_in) *next_in = dz;
 }
 
 // rst*norm, LeakyReLU, F.normalize, layer sum, next layer's input (Model.py:165-172,67-70).
-__device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const row_ctx &rc, f32x4 acc, int l) {
-  if (T.flags & DG_EPI_BWD) return epilogue_bwd(T, row, rc, acc, l);
+__device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const row_ctx &rc, f32x4 acc, int l,
+                                         f32x4 *next_in = nullptr) {
+  if (T.flags & DG_EPI_BWD) return epilogue_bwd(T, row, rc, acc, l, next_in);
   if (T.partial_out != nullptr && row >= T.partial_from) {  // another rank holds the rest of this row
     reinterpret_cast<f32x4 *>(T.partial_out)[(size_t)(row - T.partial_from) * (DG_D / 4) + l] = acc;
     return;
@@ -236,6 +242,7 @@ __device__ __forceinline__ void epilogue(const dg_task_dev &T, int row, const ro
     f32x4 e = (T.flags & DG_OUT_NORM) ? yn : y;
     if (T.flags & DG_OUT_PRESCALE) e *= dsrc;
     store_stream(T.e_out, o, e);
+    if (next_in) *next_in = e;
   }
 }
 
@@ -643,6 +650,56 @@ __global__ __launch_bounds__(64 * kDenseWaves) void dense_rows_kernel(const dg_t
   }
 }
 
+// hi / mid / lo of one fp32 value: three bf16 numbers (upper 16 bits each) whose sum is the value exactly.
+__device__ __forceinline__ void split3(float x, unsigned short &hi, unsigned short &mid, unsigned short &lo) {
+  const unsigned hb = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+  const float r1 = x - __builtin_bit_cast(float, hb);
+  const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+  const float r2 = r1 - __builtin_bit_cast(float, mb);
+  hi = (unsigned short)(hb >> 16);
+  mid = (unsigned short)(mb >> 16);
+  lo = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+}
+
+// Does this task leave (DG_OUT_PLANES) / find (DG_IN_PLANES) its graph's table as bf16 planes?  Only graphs on the
+// bitmap path whose rows have at most 16 column ranges (one 16-lane group then adds a row's slab rows in the order
+// hub_reduce_kernel does); both sides of the hand-over decide by this same rule.
+__host__ __device__ __forceinline__ bool planes_path(const dg_task_dev &t, int flag) {
+  return t.dense_splits > 0 && t.dense_splits <= 16 && (t.flags & flag) != 0;
+}
+
+// hub_reduce_kernel for the rows of a bitmap graph whose output the same graph gathers next (DG_OUT_PLANES): a
+// workgroup takes one chunk of 64 rows, a 16-lane group per row -- the row's slab rows added in range order (none:
+// the row-wise first step of a backward pass), then the usual epilogue -- and also leaves the stored values as the
+// three bf16 planes dense_rows_kernel reads (what dense_split_kernel would make of them: the next layer over this
+// graph, flagged DG_IN_PLANES, needs no split launch).
+__global__ __launch_bounds__(1024) void dense_reduce_kernel(const dg_task_batch batch) {
+  __shared__ unsigned short tr[3][64][72];   // [plane][feature][row of the chunk]
+  int ti = 0;
+  for (int k = 0; k < batch.n_tasks; ++k)
+    if (planes_path(batch.t[k], DG_OUT_PLANES) && (int)blockIdx.x >= batch.t[k].red_blk_begin) ti = k;
+  const dg_task_dev &T = batch.t[__builtin_amdgcn_readfirstlane(ti)];
+  const int c = blockIdx.x - T.red_blk_begin, r = threadIdx.x >> 4, l = threadIdx.x & 15, row = 64 * c + r;
+  f32x4 e = {0.f, 0.f, 0.f, 0.f};   // rows beyond the table: zeros, as dense_split_kernel pads
+  if (row < T.n) {
+    const row_ctx rc = load_row_ctx(T, row, l);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (T.red_parts > 0)
+      gather_rows<false, false>(table_rsrc(T.slab, T.n_seg), nullptr, nullptr, row * T.red_parts, (row + 1) * T.red_parts, 16, l, acc);
+    epilogue(T, row, rc, acc, l, &e);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split3(e[j], tr[0][4 * l + j][r], tr[1][4 * l + j][r], tr[2][4 * l + j][r]);
+  __syncthreads();
+  unsigned char *planes = reinterpret_cast<unsigned char *>(T.dense_x);
+  const unsigned row_bytes = (unsigned)T.dense_chunks * 128u;
+  for (unsigned idx = threadIdx.x; idx < 3 * 512; idx += 1024) {
+    const unsigned p = idx >> 9, f = (idx >> 3) & 63, q = idx & 7;
+    *reinterpret_cast<u32x4 *>(planes + (size_t)(p * 64 + f) * row_bytes + (unsigned)c * 128u + q * 16u) =
+        *reinterpret_cast<const u32x4 *>(&tr[p][f][8 * q]);
+  }
+}
+
 // The table of a dense graph as dense_rows_kernel reads it: times the norm of the gathered node when the caller's is
 // not scaled yet (the first layer), cut into three bf16 planes that add up to the fp32 value exactly -- truncation
 // keeps every remainder representable: hi = the value's upper 16 bits, mid = those of value - hi, lo = the rest,
@@ -651,7 +708,7 @@ __global__ __launch_bounds__(64 * kDenseWaves) void dense_rows_kernel(const dg_t
 __global__ __launch_bounds__(256) void dense_split_kernel(const dg_task_batch batch) {
   __shared__ unsigned short tr[3][64][72];   // [plane][feature][row of the chunk]
   const dg_task_dev &T = batch.t[blockIdx.y];
-  if (T.dense_splits <= 0 || (int)blockIdx.x >= T.dense_chunks) return;   // (the whole workgroup)
+  if (T.dense_splits <= 0 || (int)blockIdx.x >= T.dense_chunks || planes_path(T, DG_IN_PLANES)) return;   // (the whole workgroup)
   const int c = blockIdx.x, r = threadIdx.x >> 2, f0 = (threadIdx.x & 3) * 16, row = 64 * c + r;
   const bool scale = !(T.flags & DG_IN_PRESCALED);
   float s = 0.f;
@@ -665,15 +722,8 @@ __global__ __launch_bounds__(256) void dense_split_kernel(const dg_task_batch ba
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float x = v[e];
-      const unsigned hb = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
-      const float r1 = x - __builtin_bit_cast(float, hb);
-      const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-      const float r2 = r1 - __builtin_bit_cast(float, mb);
       const int f = f0 + 4 * j + e;
-      tr[0][f][r] = (unsigned short)(hb >> 16);
-      tr[1][f][r] = (unsigned short)(mb >> 16);
-      tr[2][f][r] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+      split3(v[e], tr[0][f][r], tr[1][f][r], tr[2][f][r]);
     }
   }
   __syncthreads();
@@ -720,6 +770,10 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   if (in.e_out == in.x) return dg_fail(DG_ERR_ARG, "layer task: e_out must not alias x");
   if ((in.flags & DG_ACC_REBUILD) && (!(in.flags & DG_IN_PRESCALED) || !in.acc_out))
     return dg_fail(DG_ERR_ARG, "layer task: DG_ACC_REBUILD needs DG_IN_PRESCALED and acc_in/acc_out");
+  if ((in.flags & DG_OUT_PLANES) && !in.e_out)
+    return dg_fail(DG_ERR_ARG, "layer task: DG_OUT_PLANES needs e_out (the planes are a second form of it)");
+  if ((in.flags & DG_IN_PLANES) && !(in.flags & DG_IN_PRESCALED))
+    return dg_fail(DG_ERR_ARG, "layer task: DG_IN_PLANES needs DG_IN_PRESCALED (the planes hold the table as it was stored)");
   if (g->weighted && (transpose || (in.flags & (DG_IN_PRESCALED | DG_EPI_BWD))))
     return dg_fail(DG_ERR_ARG, "layer task: a weighted operator runs forward only, over a table that is not scaled yet");
   const dg_csr &c = transpose ? g->bwd : g->fwd;
@@ -729,6 +783,7 @@ int fill_task(const dg_layer_task &in, int transpose, dg_task_dev &o) {
   o.win_blk_begin = 0; o.win_blk_count = 0;
   o.dense_bits = c.dense_bits; o.dense_x = g->dense_x; o.dense_splits = c.dense_splits; o.dense_chunks = c.dense_chunks;
   o.dense_cps = c.dense_cps; o.dense_tiles = c.dense_tiles; o.dense_blk_begin = 0;
+  o.red_blk_begin = 0; o.red_parts = c.dense_splits;
   o.colidx = c.colidx; o.head = c.head; o.hub_desc = c.hub_desc; o.seg_desc = c.seg_desc; o.gseg_desc = c.gseg_desc;
   o.colscale = c.colscale; o.head_scale = c.head_scale;
   o.dinv_row = transpose ? g->dinv_src : g->dinv_dst;
@@ -773,7 +828,7 @@ void apportion(int total, const double *w, int n, int32_t *cnt) {
 
 int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_t stream) {
   const int n_tasks = batch.n_tasks;
-  int32_t blocks = 0, hub_blocks = 0;
+  int32_t blocks = 0, hub_blocks = 0, red_blocks = 0;
   // which rows this call computes (row-sharded runs may ask for the partial-sum rows and the rest separately)
   constexpr int32_t kRowsMask = DG_ROWS_PARTIAL_ONLY | DG_ROWS_FULL_ONLY;
   const int32_t rows_sel = batch.t[0].flags & kRowsMask;
@@ -801,7 +856,9 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     t.blk_begin = blocks;
     t.hub_blk_begin = hub_blocks;
     blocks += (t.n_seg_slots >> 2) + (t.n_gseg_slots >> 4) + ((t.n_group + 15) >> 4);
-    hub_blocks += t.lds_split > 0 ? t.n_hub : (t.n_hub + 3) >> 2;
+    t.red_blk_begin = red_blocks;
+    if (planes_path(t, DG_OUT_PLANES)) red_blocks += t.dense_chunks;   // dense_reduce_kernel instead of hub_reduce_kernel
+    else hub_blocks += t.lds_split > 0 ? t.n_hub : (t.n_hub + 3) >> 2;
   }
   // workgroups of the two LDS kernels: one per CU in total each, shared out by the tasks' work
   int32_t lds_blocks = 0, lds_rows_max = 0, win_blocks = 0;
@@ -849,7 +906,7 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
       }
     }
   }
-  int32_t dense_blocks = 0, dense_chunks_max = 0;
+  int32_t dense_blocks = 0, dense_chunks_max = 0;   // (dense_chunks_max: of the tasks whose table still has to be split)
   for (int k = 0; k < n_tasks; ++k) {
     dg_task_dev &t = batch.t[k];
     t.dense_blk_begin = dense_blocks;
@@ -857,7 +914,7 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
       for (int j = 0; j < k; ++j)
         if (graphs[j] == graphs[k]) return dg_fail(DG_ERR_ARG, "layer tasks %d and %d share a dense graph (one slab per graph)", j, k);
       dense_blocks += ((t.dense_tiles + kDenseWaves - 1) / kDenseWaves) * t.dense_splits;
-      dense_chunks_max = max(dense_chunks_max, t.dense_chunks);
+      if (!planes_path(t, DG_IN_PLANES)) dense_chunks_max = max(dense_chunks_max, t.dense_chunks);
     }
   }
   for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
@@ -866,7 +923,7 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
   constexpr int32_t kRideAlongBlocks = 1024;
   batch.gather_blocks = (dense_blocks > 0 && blocks <= kRideAlongBlocks) ? blocks : 0;
   if (dense_blocks > 0) {
-    hipLaunchKernelGGL(dense_split_kernel, dim3(dense_chunks_max, n_tasks), dim3(256), 0, stream, batch);
+    if (dense_chunks_max > 0) hipLaunchKernelGGL(dense_split_kernel, dim3(dense_chunks_max, n_tasks), dim3(256), 0, stream, batch);
     hipLaunchKernelGGL(dense_rows_kernel, dim3(batch.gather_blocks + dense_blocks), dim3(64 * kDenseWaves), 0, stream, batch);
     if (batch.gather_blocks > 0) blocks = 0;
   }
@@ -886,6 +943,7 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
   // (under DG_ROWS_*_ONLY no task has gcn_layer_kernel rows, and every hub row is a partial-sum row)
   if (blocks > 0) hipLaunchKernelGGL(gcn_layer_kernel, dim3(blocks), dim3(256), 0, stream, batch);
   if (hub_blocks > 0 && partial_rows) hipLaunchKernelGGL(hub_reduce_kernel, dim3(hub_blocks), dim3(256), 0, stream, batch);
+  if (red_blocks > 0) hipLaunchKernelGGL(dense_reduce_kernel, dim3(red_blocks), dim3(1024), 0, stream, batch);
   DG_HIP(hipGetLastError());
   return 0;
 }
@@ -976,7 +1034,7 @@ extern "C" int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32
   dg_task_batch gather, rowwise;
   const dg_graph *ggraphs[DG_MAX_TASKS];
   gather.n_tasks = rowwise.n_tasks = 0;
-  int32_t row_blocks = 0;
+  int32_t row_blocks = 0, row_red_blocks = 0;
   for (int k = 0; k < n_tasks; ++k) {
     const dg_bwd_task &b = tasks[k];
     if (!b.graph || !b.w_out) return dg_fail(DG_ERR_ARG, "backward task %d: NULL graph or output", k);
@@ -987,7 +1045,8 @@ extern "C" int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32
       return dg_fail(DG_ERR_ARG, "backward task %d: DG_BWD_NORM_FEED needs row_norm", k);
     dg_layer_task lt;
     lt.graph = b.graph; lt.x = b.w_in ? b.w_in : b.w_out; lt.e_out = b.w_out; lt.acc_in = nullptr; lt.acc_out = nullptr;
-    lt.flags = DG_IN_PRESCALED | DG_EPI_BWD | (b.flags & DG_BWD_SAVED_PRESCALED); lt.slope = b.slope;
+    lt.flags = DG_IN_PRESCALED | DG_EPI_BWD | (b.flags & (DG_BWD_SAVED_PRESCALED | DG_OUT_PLANES)); lt.slope = b.slope;
+    if (b.w_in) lt.flags |= b.flags & DG_IN_PLANES;
     if (b.e_saved) lt.flags |= b.flags & DG_BWD_NORM_FEED;
     lt.partial_out = nullptr; lt.partial_from = 0; lt.row_norm_out = nullptr;
     dg_task_batch &dst = b.w_in ? gather : rowwise;
@@ -1001,13 +1060,17 @@ extern "C" int dg_gcn_layer_bwd(const dg_bwd_task *tasks, int32_t n_tasks, int32
       ggraphs[dst.n_tasks] = b.graph;
     } else {
       t.blk_begin = row_blocks;
-      row_blocks += (t.n + 15) >> 4;
+      t.red_blk_begin = row_red_blocks;
+      t.red_parts = 0;   // nothing to add up: the epilogue alone
+      if (planes_path(t, DG_OUT_PLANES)) row_red_blocks += t.dense_chunks;
+      else row_blocks += (t.n + 15) >> 4;
     }
     dst.n_tasks++;
   }
   if (rowwise.n_tasks > 0) {
     for (int k = rowwise.n_tasks; k < DG_MAX_TASKS; ++k) rowwise.t[k] = rowwise.t[0];
-    hipLaunchKernelGGL(rowwise_kernel, dim3(row_blocks), dim3(256), 0, (hipStream_t)stream, rowwise);
+    if (row_blocks > 0) hipLaunchKernelGGL(rowwise_kernel, dim3(row_blocks), dim3(256), 0, (hipStream_t)stream, rowwise);
+    if (row_red_blocks > 0) hipLaunchKernelGGL(dense_reduce_kernel, dim3(row_red_blocks), dim3(1024), 0, (hipStream_t)stream, rowwise);
     DG_HIP(hipGetLastError());
   }
   if (gather.n_tasks > 0) return launch_batch(gather, ggraphs, (hipStream_t)stream);

@@ -17,8 +17,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from ._lib import (DG_ACC_REBUILD, DG_BWD_NORM_FEED, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_NORM,
-                   DG_OUT_PRESCALE)
+from ._lib import (DG_ACC_REBUILD, DG_BWD_NORM_FEED, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PLANES, DG_IN_PRESCALED, DG_OUT_NORM,
+                   DG_OUT_PLANES, DG_OUT_PRESCALE)
 from .diffusion import Denoise, GaussianDiffusion
 from .layers import UUGCNLayer
 
@@ -89,6 +89,13 @@ class _LossHeadFn(torch.autograd.Function):
         return d_e, d_e, d_row_loss, d_w, d_b, None, None
 
 
+def _plane_flags(graphs):
+    """(out, in) hints for layer tasks whose output the same graph gathers next: bitmap graphs keep that table as
+    bf16 planes, and the producing launch can leave them ready.  A graph handle holds ONE set of planes, so the hints
+    are only given when every channel has a handle of its own."""
+    return (DG_OUT_PLANES, DG_IN_PLANES) if len({id(g) for g in graphs}) == len(graphs) else (0, 0)
+
+
 def _launch_distinct(tasks, launch) -> None:
     """Graphs that share a handle cannot share a launch (one hub slab per handle)."""
     seen, batch = set(), []
@@ -121,18 +128,19 @@ class _PropagateFn(torch.autograd.Function):
         ref = saved[0][0]
         d_sum = [torch.zeros_like(ref) if d is None else d.contiguous() for d in d_sums]
         w = [None] * len(graphs)
+        planes_out, planes_in = _plane_flags(graphs)
         for l in range(L, 0, -1):
             tasks = []
             for g, graph in enumerate(graphs):
                 out = torch.empty_like(ref)
-                flags = DG_BWD_NORM_FEED | (DG_BWD_SAVED_PRESCALED if l < L else 0)
+                flags = DG_BWD_NORM_FEED | (DG_BWD_SAVED_PRESCALED if l < L else 0) | planes_out | (planes_in if l < L else 0)
                 tasks.append(ops.BwdTask(graph, w[g], saved[g][l - 1], d_sum[g], out, flags, slope, norms[g][l - 1]))
                 w[g] = out
             _launch_distinct(tasks, ops.gcn_layer_bwd_batched)
         tasks = []
         for g, graph in enumerate(graphs):
             out = torch.empty_like(ref)
-            tasks.append(ops.BwdTask(graph, w[g], None, None, out, 0, slope))
+            tasks.append(ops.BwdTask(graph, w[g], None, None, out, planes_in, slope))
             w[g] = out
         _launch_distinct(tasks, ops.gcn_layer_bwd_batched)
         # every channel's layer sum starts from the same table (Model.py:48-50)
@@ -173,12 +181,13 @@ class HGDM(nn.Module):
         prev: List[Optional[torch.Tensor]] = [None] * len(he_adjs)
         saved = [[] for _ in he_adjs]
         norms = [[] for _ in he_adjs]
+        planes_out, planes_in = _plane_flags(he_adjs)
         for l in range(L):
             last = l == L - 1
             tasks = []
             for g, graph in enumerate(he_adjs):
                 e_out = None if (last and not keep) else torch.empty_like(embed)
-                flags = (DG_IN_PRESCALED if l > 0 else 0) | DG_OUT_NORM | (0 if last else DG_OUT_PRESCALE)
+                flags = (DG_IN_PRESCALED | planes_in if l > 0 else 0) | DG_OUT_NORM | (0 if last else DG_OUT_PRESCALE | planes_out)
                 if l == 0 and L >= 2:      # no running sum from the first layer; the second rebuilds it
                     acc_in = acc_out = None
                 elif l == 1:

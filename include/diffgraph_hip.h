@@ -116,6 +116,13 @@ enum { DG_IN_PRESCALED = 1, DG_OUT_NORM = 2, DG_OUT_PRESCALE = 4, DG_ACC_REBUILD
  * running sum; acc_in points at the layer-0 table e0 and the sum so far is rebuilt per row as
  * e0[i] + normalize(x[i])  (x[i] = dinv_src[i] * E_1[i], so normalize(x[i]) is the first
  * layer's normalised activation).  Saves one table write and one cold table read per graph. */
+enum { DG_OUT_PLANES = 0x200, DG_IN_PLANES = 0x400 };
+/* Graphs on the bitmap path (dense graphs) gather from a copy of the table cut into three bf16 planes, made by a
+ * launch of its own before each layer.  DG_OUT_PLANES: this task's output is what the NEXT layer task over the same
+ * graph gathers -- leave it as planes too (e_out is still written); DG_IN_PLANES (with DG_IN_PRESCALED) on that next
+ * task: the planes are in place, skip the cut.  Both are hints: ignored for graphs on other paths (and for bitmap
+ * graphs with more than 16 column ranges per row), by the same rule on both sides, so a pair of tasks always agrees.
+ * Also accepted in dg_bwd_task::flags, where the output is w_out and the gather source w_in.  Same bits either way. */
 enum { DG_ROWS_PARTIAL_ONLY = 64, DG_ROWS_FULL_ONLY = 128 };
 /* Row-sharded runs may cut a layer call in two so that the exchange of the partial sums overlaps
  * the rest of the layer: a call with DG_ROWS_PARTIAL_ONLY computes only the rows >= partial_from
