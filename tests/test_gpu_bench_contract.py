@@ -51,3 +51,12 @@ def test_gpus_flag_starts_its_own_ranks():
     r = _run("--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", env={"DG_DIST_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0
     assert r["config"]["speedup_over_1gpu"] > 0 and "x2" in r["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("flags, launch", [((), "hip-graph replay"), (("--no-graph",), "eager")])
+def test_nc_training_step_leg(flags, launch):
+    """`--workload nc_train_dblp`: one DiffGraph_NC training step on the committed DBLP data, replayed as a HIP graph
+    by default; the same kind of line, finite losses."""
+    r = _run("--workload", "nc_train_dblp", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", *flags)
+    assert r["config"]["launch"] == launch and r["unit"] == "edges/s" and r["value"] > 0 and r["n_gpus"] == 1
+    assert all(x == x and abs(x) < 1e3 for x in r["config"]["loss"]) and r["roofline"]["bound"] == "hbm"
