@@ -17,12 +17,12 @@ Importing the package does not load the shared library; the first op does, and r
 DiffGraphHipError if it is missing (there is no CPU fallback).
 """
 from ._lib import DiffGraphHipError  # noqa: F401
-from .graph import CSRGraph  # noqa: F401
+from .graph import CSRGraph, GraphSet  # noqa: F401
 from .layers import DGLLayer, UUGCNLayer  # noqa: F401
 from .diffusion import Denoise, GaussianDiffusion  # noqa: F401
 from . import model_rec as rec  # noqa: F401
 from . import model_nc as nc  # noqa: F401
 from . import data, evaluate, io, metapath, ops, optim, sampling, train, train_nc  # noqa: F401
 
-__all__ = ["CSRGraph", "DGLLayer", "UUGCNLayer", "Denoise", "GaussianDiffusion", "rec", "nc", "ops", "data",
+__all__ = ["CSRGraph", "GraphSet", "DGLLayer", "UUGCNLayer", "Denoise", "GaussianDiffusion", "rec", "nc", "ops", "data",
            "DiffGraphHipError"]

@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffgraph_hip.so")
-SOURCES = ["graph.hip", "spmm.hip", "diffusion.hip", "wgrad.hip", "losshead.hip", "eval.hip", "sampling.hip", "spgemm.hip", "optim.hip", "linear.hip"]
-HEADERS = [os.path.join(CSRC, "dg_internal.h"), os.path.join(CSRC, "dg_philox.h"), os.path.join(CSRC, "dg_wgrad.h"), os.path.join(HERE, "..", "include", "diffgraph_hip.h")]
+SOURCES = ["graph.hip", "spmm.hip", "fused.hip", "diffusion.hip", "wgrad.hip", "losshead.hip", "eval.hip", "sampling.hip", "spgemm.hip", "optim.hip", "linear.hip"]
+HEADERS = [os.path.join(CSRC, "dg_internal.h"), os.path.join(CSRC, "dg_gather.h"), os.path.join(CSRC, "dg_philox.h"), os.path.join(CSRC, "dg_wgrad.h"), os.path.join(HERE, "..", "include", "diffgraph_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -134,3 +134,53 @@ class CSRGraph:
             self.close()
         except Exception:
             pass
+
+
+class GraphSet:
+    """2..4 symmetric graphs over the same nodes behind ONE row schedule (dg_graphset): a propagation layer over the
+    set sums row r's neighbours in every graph back to back and writes the first graph's layer sum and the sum of the
+    others' once each -- HGDM.forward's target graph and behaviour graphs (DiffGraph-Rec/Model.py:61-87).  The set
+    copies what it needs from the graphs."""
+
+    def __init__(self, graphs, group_max: int = 0, seg_len: int = 0, device=None):
+        graphs = list(graphs)
+        arr = (C.c_void_p * len(graphs))(*[g.handle for g in graphs])
+        h = C.c_void_p()
+        with _lib.device_guard(device):
+            rc = _lib.load().dg_graphset_create(arr, len(graphs), int(group_max), int(seg_len), C.byref(h))
+        _lib.check(rc, "dg_graphset_create")
+        self._h = h
+        self._n, self._g = graphs[0].num_nodes(), len(graphs)
+        self._nnz = [g.num_edges() for g in graphs]
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if self._h is None:
+            raise _lib.DiffGraphHipError("graph set already destroyed")
+        return self._h
+
+    def num_nodes(self) -> int:
+        return self._n
+
+    def num_graphs(self) -> int:
+        return self._g
+
+    def num_edges(self):
+        """Directed edges per graph."""
+        return list(self._nnz)
+
+    def counts(self) -> dict:
+        c = (C.c_int32 * 6)()
+        _lib.check(_lib.load().dg_graphset_counts(self.handle, c), "dg_graphset_counts")
+        return {"n": c[0], "graphs": c[1], "n_hub": c[2], "n_seg": c[3], "quad_max": c[4], "seg_len": c[5]}
+
+    def close(self) -> None:
+        if self._h is not None:
+            _lib.load().dg_graphset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .graph import CSRGraph
+from .graph import CSRGraph, GraphSet
 from ._lib import DG_ACC_REBUILD, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
 from .diffusion import Denoise, GaussianDiffusion, dropout_args, dropout_rate
 from .layers import DGLLayer
@@ -36,6 +36,16 @@ def pairPredict(ancEmbeds, posEmbeds, negEmbeds):  # DiffGraph-Rec/Utils/Utils.p
     return (ancEmbeds * posEmbeds).sum(-1) - (ancEmbeds * negEmbeds).sum(-1)
 
 
+def _same_objects(a, b) -> bool:
+    return a is not None and len(a) == len(b) and all(x is y for x, y in zip(a, b))
+
+
+class _SavedStack(list):
+    """Per-graph [E_1, E_2] views of a forward pass over a graph set, with the set and the stacked tensors."""
+    gset = None
+    stacked = None
+
+
 class _PropagateFn(torch.autograd.Function):
     """HGDM.propagate as one differentiable op.  The forward keeps, per graph, every layer's
     activation (scaled by the source norm, as the next layer consumed it; the last layer's
@@ -46,6 +56,8 @@ class _PropagateFn(torch.autograd.Function):
         e0 = e0.contiguous()
         ui, het, saved = model._propagate(e0, keep=True)
         ctx.model, ctx.saved = model, saved
+        # (a forward over the graph set keeps the graphs' activations stacked: the backward then walks the set too)
+        ctx.gset, ctx.stacked = getattr(saved, "gset", None), getattr(saved, "stacked", None)
         return ui, het
 
     @staticmethod
@@ -58,7 +70,16 @@ class _PropagateFn(torch.autograd.Function):
         d_het = torch.zeros_like(ref) if d_het is None else d_het.contiguous()
         d_sum = [d_ui] + [d_het] * (len(graphs) - 1)
         w = [None] * len(graphs)
-        for l in range(L, 0, -1):
+        stack = None
+        if ctx.gset is not None:
+            # both steps over the set: d_ui / d_het are read once per row, not once per graph
+            e1, e2 = ctx.stacked
+            w2 = torch.empty_like(e2)
+            ops.set_layer_bwd_top(ctx.gset, e2, d_ui, d_het, w2, slope)
+            stack = torch.empty_like(e1)
+            ops.set_layer_bwd_mid(ctx.gset, w2, e1, d_ui, d_het, stack, slope)
+            w = [stack[g] for g in range(len(graphs))]
+        for l in range(L if ctx.gset is None else 0, 0, -1):
             tasks = []
             # the tables of the step before the last lie one after the other: the merged last step reads them as one
             stack = torch.empty((len(graphs),) + tuple(ref.shape), dtype=ref.dtype, device=ref.device) if l == 1 else None
@@ -203,6 +224,8 @@ class HGDM(nn.Module):
         self.side_overlap = True       # False: side_work() stays on the current stream (one kernel at a time, e.g. to time them)
         self.merge_last_step = True    # False: the backward's last propagation step runs graph by graph (see merged_last_step)
         self._merged, self._merged_key = None, None
+        self.fuse_graphs = True        # False: one layer task per graph instead of the row walk over the graph set (graph_set)
+        self._gset, self._gset_graphs = None, None
 
     def merged_last_step(self) -> Optional[CSRGraph]:
         """The last step of the backward pass is linear: d e0 gets sum_g A_g^T dZ_g, with no activation or
@@ -214,10 +237,9 @@ class HGDM(nn.Module):
         if not self.merge_last_step:
             return None
         graphs = [self.target_adj] + self.behavior_mats
-        key = tuple(id(g) for g in graphs)
-        if self._merged is None or self._merged_key != key:      # (graphs swapped since: build it anew)
+        if self._merged is None or not _same_objects(self._merged_key, graphs):      # (graphs swapped since: build it anew)
             n = self.n_user + self.n_item
-            self._merged, self._merged_key = False, key
+            self._merged, self._merged_key = False, list(graphs)   # the graphs themselves: an id() can be handed out again
             if all(g.is_symmetric and g.schedule()["lds_split"] == 0 and g.schedule()["dense_splits"] == 0 for g in graphs) \
                     and len(graphs) * n * self.n_hid * 4 < 2 ** 32:
                 rows, cols, weights = [], [], []
@@ -303,7 +325,51 @@ class HGDM(nn.Module):
         ui, het, _ = self._propagate(e0.detach().contiguous(), keep=False)
         return ui, het
 
+    def graph_set(self) -> Optional[GraphSet]:
+        """The target graph and the behaviour graphs behind one row schedule (GraphSet), when the propagation can run
+        over it: two layers, 2..4 symmetric graphs on the plain gather path.  Built at first use; None otherwise and
+        when switched off (fuse_graphs = False: one task per graph, as for every other shape)."""
+        if not self.fuse_graphs or self.n_layers != 2:
+            return None
+        graphs = [self.target_adj] + self.behavior_mats
+        if self._gset is None or not _same_objects(self._gset_graphs, graphs):      # (graphs swapped since: build it anew)
+            n = self.n_user + self.n_item
+            self._gset, self._gset_graphs = False, list(graphs)
+            if 2 <= len(graphs) <= 4 and len(graphs) * n * self.n_hid * 4 < 2 ** 32 and all(
+                    g.num_nodes() == n and g.is_symmetric and g.schedule()["lds_split"] == 0
+                    and g.schedule()["dense_splits"] == 0 for g in graphs):
+                self._gset = GraphSet(graphs, device=self.embedding_table.device)
+        return self._gset or None
+
+    def _propagate_set(self, gset: GraphSet, e0: torch.Tensor, keep: bool):
+        """Both layers over the graph set: two launches (+ one each for the rows summed in pieces)."""
+        graphs = [self.target_adj] + self.behavior_mats
+        slope = float(self.act.negative_slope)
+        G, n = len(graphs), e0.shape[0]
+        hook = getattr(self, "layer_hook", None)
+        e1 = torch.empty((G, n, DG_D), dtype=e0.dtype, device=e0.device)
+        e2 = torch.empty_like(e1) if keep else None
+        ui, het = torch.empty_like(e0), torch.empty_like(e0)
+        if hook is not None:    # what the launch does, per graph, in the terms of the task-per-graph path
+            hook("begin", 0, [ops.LayerTask(g, e0, e1[k], None, None, DG_OUT_PRESCALE, slope, shared_rows=True)
+                              for k, g in enumerate(graphs)])
+        ops.set_layer_first(gset, e0, e1, slope)
+        if hook is not None:
+            hook("end", 0, None)
+            hook("begin", 1, [ops.LayerTask(g, e1[k], None if e2 is None else e2[k], e0, ui if k == 0 else het,
+                                            DG_IN_PRESCALED | DG_ACC_REBUILD, slope, shared_rows=True)
+                              for k, g in enumerate(graphs)])
+        ops.set_layer_last(gset, e1, e0, ui, het, e2, slope)
+        if hook is not None:
+            hook("end", 1, None)
+        saved = _SavedStack([[e1[k], e2[k]] for k in range(G)] if keep else [])
+        saved.gset, saved.stacked = gset, (e1, e2)
+        return ui, het, saved
+
     def _propagate(self, e0: torch.Tensor, keep: bool):
+        gset = self.graph_set()
+        if gset is not None:
+            return self._propagate_set(gset, e0, keep)
         graphs = [self.target_adj] + self.behavior_mats
         slope = float(self.act.negative_slope)
         L = self.n_layers

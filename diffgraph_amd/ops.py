@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import DG_D, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE, DiffGraphHipError
-from .graph import CSRGraph
+from .graph import CSRGraph, GraphSet
 
 
 def _table(x: torch.Tensor, name: str, rows: Optional[int] = None) -> torch.Tensor:
@@ -69,6 +69,7 @@ class LayerTask:
     partial_out: Optional[torch.Tensor] = None   # sharded runs: raw neighbour sums of rows >= partial_from
     partial_from: int = 0
     row_norm_out: Optional[torch.Tensor] = None  # [n] ||y|| before normalisation (for a normalised-feed backward)
+    shared_rows: bool = False   # descriptive only: the task is one graph's share of a launch over a GraphSet
 
 
 def _row_vector(v: torch.Tensor, name: str, n: int) -> None:
@@ -215,6 +216,68 @@ def prepare_sum_tables(tables: Sequence[torch.Tensor], out: torch.Tensor):
     def launch(_keep=keep):
         _lib.check(fn(ptrs, n_in, out.data_ptr(), out.numel(), _lib.stream_ptr(out.device)), "dg_sum_tables")
     return launch
+
+
+def _stacked(x: torch.Tensor, name: str, gset: GraphSet) -> torch.Tensor:
+    want = (gset.num_graphs(), gset.num_nodes(), DG_D)
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or tuple(x.shape) != want \
+            or not x.is_contiguous():
+        raise DiffGraphHipError(f"{name}: expected a contiguous float32 GPU tensor of shape {want}")
+    return x
+
+
+def set_layer_first(gset: GraphSet, x: torch.Tensor, e_out: torch.Tensor, slope: float = 0.5) -> None:
+    """First layer over all graphs of the set from the one table x [n,64]: e_out[g] = the activation of graph g,
+    times the row's source norm (what the next layer gathers)."""
+    _table(x, "x", gset.num_nodes())
+    _stacked(e_out, "e_out", gset)
+    rc = _lib.load().dg_set_layer_first(gset.handle, x.data_ptr(), e_out.data_ptr(), float(slope), DG_D, _lib.stream_ptr(x.device))
+    _lib.check(rc, "dg_set_layer_first")
+
+
+def set_layer_last(gset: GraphSet, x: torch.Tensor, e0: torch.Tensor, sum_first: torch.Tensor, sum_rest: torch.Tensor,
+                   e_out: Optional[torch.Tensor] = None, slope: float = 0.5) -> None:
+    """Second (last) layer over the set: gathers graph g's rows from x[g] (set_layer_first's output), writes the
+    first graph's layer sum e0 + normalize(E_1) + normalize(E_2) and the sum of the other graphs' layer sums, and --
+    for a backward pass -- the activations E_2 into e_out[g]."""
+    n = gset.num_nodes()
+    _stacked(x, "x", gset)
+    _table(e0, "e0", n)
+    _table(sum_first, "sum_first", n)
+    _table(sum_rest, "sum_rest", n)
+    if e_out is not None:
+        _stacked(e_out, "e_out", gset)
+    rc = _lib.load().dg_set_layer_last(gset.handle, x.data_ptr(), e0.data_ptr(), sum_first.data_ptr(), sum_rest.data_ptr(),
+                                       _ptr(e_out), float(slope), DG_D, _lib.stream_ptr(x.device))
+    _lib.check(rc, "dg_set_layer_last")
+
+
+def set_layer_bwd_top(gset: GraphSet, e_saved: torch.Tensor, d_first: torch.Tensor, d_rest: torch.Tensor,
+                      w_out: torch.Tensor, slope: float = 0.5) -> None:
+    """Backward through the last layer's LeakyReLU / normalize / layer sum for every graph of the set (no gather)."""
+    n = gset.num_nodes()
+    _stacked(e_saved, "e_saved", gset)
+    _stacked(w_out, "w_out", gset)
+    _table(d_first, "d_first", n)
+    _table(d_rest, "d_rest", n)
+    rc = _lib.load().dg_set_layer_bwd_top(gset.handle, e_saved.data_ptr(), d_first.data_ptr(), d_rest.data_ptr(),
+                                          w_out.data_ptr(), float(slope), DG_D, _lib.stream_ptr(w_out.device))
+    _lib.check(rc, "dg_set_layer_bwd_top")
+
+
+def set_layer_bwd_mid(gset: GraphSet, w_in: torch.Tensor, e_saved: torch.Tensor, d_first: torch.Tensor,
+                      d_rest: torch.Tensor, w_out: torch.Tensor, slope: float = 0.5) -> None:
+    """Backward through the first layer for every graph of the set: the transposed propagation of w_in (the top
+    step's output) fused with the LeakyReLU / normalize backward at e_saved = set_layer_first's output."""
+    n = gset.num_nodes()
+    for nm, v in (("w_in", w_in), ("e_saved", e_saved), ("w_out", w_out)):
+        _stacked(v, nm, gset)
+    _table(d_first, "d_first", n)
+    _table(d_rest, "d_rest", n)
+    rc = _lib.load().dg_set_layer_bwd_mid(gset.handle, w_in.data_ptr(), e_saved.data_ptr(), d_first.data_ptr(),
+                                          d_rest.data_ptr(), w_out.data_ptr(), float(slope), DG_D,
+                                          _lib.stream_ptr(w_out.device))
+    _lib.check(rc, "dg_set_layer_bwd_mid")
 
 
 # --------------------------------------------------------------------------------------

@@ -220,6 +220,43 @@ int dg_sum_tables(const float *const *in_host, int32_t n_in, float *out, int64_t
                   void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * a2 as ONE row walk over all graphs: HGDM.forward (DiffGraph-Rec/Model.py:53-92) runs the same
+ * two-layer propagation over the target graph (Model.py:61-70) and every behaviour graph
+ * (Model.py:73-84), all from the one embedding table, and uses only the target graph's layer
+ * sum and sum(list) of the behaviour graphs' layer sums (Model.py:87,92).  A dg_graphset holds
+ * 2..4 symmetric graphs over the same nodes (graph 0 = the target graph) with ONE row schedule:
+ * a 16-lane group sums row r's neighbours in every graph back to back and applies the graphs'
+ * epilogues together, so the layer-0 row is read once per row instead of once per graph and
+ * the per-behaviour sums never reach memory.  Per-graph tables are STACKED: [graphs][n][64].
+ * With y_g = LeakyReLU_slope(dinv_g[i] * sum_{j in N_g(i)} .) as in dg_spmm_norm_act_fwd:
+ *   dg_set_layer_first:  e_out[g][i] = dinv_g[i] * y_g        (gathering dinv_g[j] * x[j], x = [n][64])
+ *   dg_set_layer_last:   S_g = (e0[i] + normalize(x[g][i])) + normalize(y_g)   (gathering x[g][j], the first call's e_out)
+ *                        sum_first[i] = S_0;  sum_rest[i] = (S_1 + S_2) + S_3;  e_out[g][i] = y_g (if not NULL)
+ * Backward (a11), with d_first / d_rest the gradients wrt sum_first / sum_rest (graph 0 takes d_first, the others
+ * d_rest) and the formulas of dg_gcn_layer_bwd:
+ *   dg_set_layer_bwd_top:  w_out[g] = dZ_2 of graph g from e_saved[g] = the last call's e_out   (no gather)
+ *   dg_set_layer_bwd_mid:  w_out[g] = dZ_1 of graph g from w_in = the top step's w_out (gathered) and
+ *                          e_saved[g] = the first call's e_out
+ * The graphs must outlive nothing: the set copies what it needs.  Calls on one set share its slab: serialise them
+ * on one stream.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dg_graphset dg_graphset;
+/* group_max: rows whose padded lists hold at most this many slots in all graphs together are summed by one group
+ * (0 = 128); seg_len as in dg_graph_create. */
+int dg_graphset_create(dg_graph *const *graphs, int32_t n_graphs, int32_t group_max, int32_t seg_len,
+                       dg_graphset **out);
+void dg_graphset_destroy(dg_graphset *set);
+/* counts_host[6] = {nodes, graphs, cut rows, slab rows, quads a group row may hold, seg_len} */
+int dg_graphset_counts(const dg_graphset *set, int32_t *counts_host);
+int dg_set_layer_first(dg_graphset *set, const float *x, float *e_out, float slope, int32_t d, void *stream);
+int dg_set_layer_last(dg_graphset *set, const float *x, const float *e0, float *sum_first, float *sum_rest,
+                      float *e_out, float slope, int32_t d, void *stream);
+int dg_set_layer_bwd_top(dg_graphset *set, const float *e_saved, const float *d_first, const float *d_rest,
+                         float *w_out, float slope, int32_t d, void *stream);
+int dg_set_layer_bwd_mid(dg_graphset *set, const float *w_in, const float *e_saved, const float *d_first,
+                         const float *d_rest, float *w_out, float slope, int32_t d, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * a6: q_sample.  Replaces GaussianDiffusion.q_sample + _extract_into_tensor
  * (DiffGraph-Rec/Model.py:302-312):  x_t[i] = sqrt_ac[t_i]*x0[i] + sqrt_1mac[t_i]*noise[i].
  * sqrt_ac / sqrt_1mac: DEVICE fp32 tables of length n_steps (the fp64 host tables cast to
