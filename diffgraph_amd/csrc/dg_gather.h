@@ -68,11 +68,20 @@ __device__ __forceinline__ void gather_rows(__amdgpu_buffer_rsrc_t xr, const int
   }
   while (p < end) {
     const int pn = p + stride;
-    int cn = -1;
+    // The next chunk's ids (and norms) are in flight while this chunk's rows load.  The load is UNCONDITIONAL (its
+    // address clamped into the list, the value dropped afterwards): a load under a branch leaves the number of
+    // requests in flight unknown to the compiler, which then waits for ALL of them before the first use of this
+    // chunk's ids -- the prefetch included.
+    int cn = pn + l;
     float sn = 0.f;
-    if (pn + l < end) {  // next chunk's ids (and norms) are in flight while this chunk's rows load
-      cn = INDEXED ? colidx[pn + l] : pn + l;
-      if (SCALE) sn = colscale[pn + l];
+    if (INDEXED) {
+      const int at = min(pn + l, end - 1);
+      cn = colidx[at];
+      if (SCALE) sn = colscale[at];
+    }
+    if (pn + l >= end) {
+      cn = -1;
+      sn = 0.f;
     }
     const int cnt = end - p;
     gather4<0, SCALE>(xr, c, s, lane_off, acc);

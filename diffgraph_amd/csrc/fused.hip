@@ -207,11 +207,13 @@ __device__ __forceinline__ void walk_group_row(__amdgpu_buffer_rsrc_t xr, const 
     }
     while (p < end) {
       const int pn = p + 16;
-      int cn = -1;
-      float sn = 0.f;
-      if (pn + l < end) {  // the next chunk's ids are on their way while this chunk's rows load
-        cn = col[pn + l];
-        if (SCALE) sn = colscale[pn + l];
+      // the next chunk's ids are on their way while this chunk's rows load (an unconditional load: see gather_rows)
+      const int at = min(pn + l, end - 1);
+      int cn = col[at];
+      float sn = SCALE ? colscale[at] : 0.f;
+      if (pn + l >= end) {
+        cn = -1;
+        sn = 0.f;
       }
       const int cnt = end - p;
       gather4<0, SCALE>(xr, cc, sc, lane_off, acc); DG_SET_MOVE(sq + 1)

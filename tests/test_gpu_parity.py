@@ -841,7 +841,11 @@ def test_sharded_propagation_matches_single_gpu(world):
     m = rec_model(wl, fx)
     m.set_embeddings(dev(ue), dev(ie))
     with torch.no_grad():
+        ui_set, het_set = m.propagate(m.embedding_table)    # the default: the row walk over the graph set
+        m.fuse_graphs = False                               # one task per graph: the kernels the sharded path runs
         ui_ref, het_ref = m.propagate(m.embedding_table)
+    assert_rows_close(ui_set, ui_ref, rtol=1e-6, what="graph set vs task per graph, target sums")
+    assert_rows_close(het_set, het_ref, rtol=1e-6, what="graph set vs task per graph, behaviour sums")
     res = _run_sharded_threads(inter, wl.n_user, wl.n_item, ue, ie, world)
     nu = wl.n_user
     ui_users = torch.cat([r[2][: r[1] - r[0]] for r in res])
@@ -874,6 +878,7 @@ def test_row_block_propagation_matches_single_gpu(world):
     e0 = torch.cat([T(fx["user_emb"]), T(fx["item_emb"])])
     m = rec_model(wl, fx)
     m.set_embeddings(dev(fx["user_emb"]), dev(fx["item_emb"]))
+    m.fuse_graphs = False     # one task per graph: the kernels and row cuts the partition runs
     with torch.no_grad():
         ui_ref, het_ref = m.propagate(m.embedding_table)
     barrier = threading.Barrier(world)

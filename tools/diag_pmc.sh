@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box: one rocprofv3 --pmc pass per counter group over tools/layer_bench.py (the fused propagation
 # layers of a Rec workload), summarised per kernel into gpurun_out/<tag>/diag_pmc.txt.
-#   tools/diag_pmc.sh TAG [workload]
+#   tools/diag_pmc.sh TAG [workload] [kernel-name pattern] [tool]     (tool: layer_bench.py or set_bench.py)
 set -o pipefail
-TAG=${1:-diag}; WL=${2:-tmall}
+TAG=${1:-diag}; WL=${2:-tmall}; PAT=${3:-gcn_layer}; TOOL=${4:-layer_bench.py}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 : > $O/diag_pmc.txt
@@ -11,9 +11,9 @@ i=0
 while read -r c; do
   [ -z "$c" ] && continue
   i=$((i+1))
-  timeout -s KILL 90 rocprofv3 --pmc $c --output-format csv -d $O/diag_$i -o p -- python $R/tools/layer_bench.py $WL 0,0 > $O/diag_$i.log 2>&1 || { echo "pass $i ($c) failed" >> $O/diag_pmc.txt; tail -3 $O/diag_$i.log >> $O/diag_pmc.txt; continue; }
+  timeout -s KILL 90 rocprofv3 --pmc $c --output-format csv -d $O/diag_$i -o p -- python $R/tools/$TOOL $WL 0,0 > $O/diag_$i.log 2>&1 || { echo "pass $i ($c) failed" >> $O/diag_pmc.txt; tail -3 $O/diag_$i.log >> $O/diag_pmc.txt; continue; }
   echo "## --pmc $c" >> $O/diag_pmc.txt
-  python $R/tools/pmc_summary.py $O/diag_$i gcn_layer >> $O/diag_pmc.txt
+  python $R/tools/pmc_summary.py $O/diag_$i $PAT >> $O/diag_pmc.txt
   rm -rf $O/diag_$i
 done <<'LIST'
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM
