@@ -31,14 +31,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
 def source_digest() -> str:
-    """Digest of the kernel sources: a traffic file counts only for the kernels it was measured on."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "diffgraph_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "diffgraph_amd", "csrc", "*.h"))):
-        with open(f, "rb") as fh:
-            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
-    return h.hexdigest()[:16]
+    """Digest of the kernel sources: a traffic file counts only for the kernels it was measured on (the loaded library
+    carries the same digest and is refused when it differs: diffgraph_amd._lib.load)."""
+    from diffgraph_amd import build
+    return build.source_digest()
 
 
 def measured_traffic(workload: str):
@@ -68,6 +64,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-workloads", default="ijcai", help="Rec workloads whose layer timings ride along in roofline.other_workloads "
+                    "(comma list; '' for none)")
+    ap.add_argument("--one-gpu-forward", default="industry", help="workload of the multi-GPU experiment (forward propagation) timed on "
+                    "this one GPU as config.<name>_1gpu_edges_per_s ('' for none)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     return ap.parse_args()
 
@@ -109,21 +109,136 @@ def layer_bytes(tasks):
     DG_ACC_REBUILD) and every table it writes."""
     from diffgraph_amd._lib import DG_IN_PRESCALED
     algo = comp = 0
-    reads, label = {}, set()
-    for t in tasks:
+    reads, writes, label = {}, {}, set()
+    for k, t in enumerate(tasks):
         n, nnz = t.graph.num_nodes(), t.graph.num_edges()
         algo += 4 * nnz + 1032 * n
         pre = bool(t.flags & DG_IN_PRESCALED)
-        comp += (4 if pre else 8) * nnz + (64 if pre else 128) * n + 12 * n
+        comp += (4 if pre else 8) * nnz
+        # row records: one per graph and row -- or, in a launch over a graph set, one per row for all its graphs
+        if not t.shared_rows or k == 0:
+            comp += (64 if pre else 128) * n
+        comp += (8 if t.shared_rows else 12) * n
         reads[t.x.data_ptr()] = 256 * n
         if t.acc_out is not None:
             reads[t.acc_in.data_ptr()] = 256 * n
-            comp += 256 * n
+            writes[t.acc_out.data_ptr()] = 256 * n       # (the behaviour graphs of a set share ONE sum table)
             label.add("sum")
         if t.e_out is not None:
-            comp += 256 * n
+            writes[t.e_out.data_ptr()] = 256 * n
             label.add("E")
-    return algo, comp + sum(reads.values()), "+".join(sorted(label))
+    return algo, comp + sum(reads.values()) + sum(writes.values()), "+".join(sorted(label))
+
+
+def time_layers(model, timer, step, iters: int, graphs):
+    """Kernel-level timing for the roofline, in the process that timed the steps: HIP events around each fused layer
+    launch of (a) the training step, launched eagerly (events cannot be read back from inside a replayed graph; the
+    kernels and their arguments are the same), and (b) the inference-mode propagation (HGDM.predict's), back to back.
+    A timed step runs its short side launches (random draws, time-bias tables, buffer clearing) BESIDE the first layer
+    launch; here they stay in line on the one stream, so that an interval holds the layer kernels alone.  Returns one
+    row per (mode, layer)."""
+    timer.records = []
+    timer.enabled = True
+    model.side_overlap = False
+    for _ in range(iters):
+        torch.cuda._sleep(10_000_000)   # the GPU spins ~5 ms while the host queues the step: launches then run back to back,
+        step()                          # and an interval holds kernel time, not the host's launch latency
+    torch.cuda.synchronize()
+    model.side_overlap = True
+    train_layers = timer.by_key()
+    timer.records = []
+    with torch.no_grad():
+        for _ in range(iters):
+            model.propagate(model.embedding_table)
+    torch.cuda.synchronize()
+    timer.enabled = False
+    infer_layers = timer.by_key()
+    timer.records = []
+    nnz = [g.num_edges() for g in graphs]
+
+    def rows(d, mode):
+        out = []
+        for (layer, writes), v in sorted(d.items()):
+            algo, comp = v["bytes"]
+            sec = v["ms"] * 1e-3
+            out.append({"mode": mode, "layer": layer + 1, "writes": writes, "launches": v["n"], "ms_per_launch": v["ms"],
+                        "bytes_algorithmic": algo, "bytes_compulsory": comp, "frac": algo / sec / 1e9 / HBM_PEAK_GBS,
+                        "frac_compulsory": comp / sec / 1e9 / HBM_PEAK_GBS, "spmm_edges_per_s": sum(nnz) / sec})
+        return out
+    return rows(train_layers, "training step (forward)") + rows(infer_layers, "inference")
+
+
+def rec_step(workload: str, device):
+    """(wl, graphs, model, timer, step): the model of a Rec workload with a LayerTimer hooked in and `step`, one
+    training step as Coach.trainEpoch runs it (DiffGraph-Rec/main.py:114-128: cal_loss -- timesteps and noise drawn
+    inside training_losses2, Model.py:352-353 --, backward, Adam) over a batch of uniform random triples, returning
+    float64[4] = loss, bprLoss, regLoss, diff_loss."""
+    import diffgraph_amd as dg
+    from diffgraph_amd.train import training_step
+    wl, graphs, model = build_rec(workload, device)
+    gen = torch.Generator().manual_seed(1)
+    B = model.args.batch
+    # (uniform random triples; `--workload epoch_tmall` runs whole epochs over the real, popularity-skewed pairs)
+    ancs = torch.randint(0, wl.n_user, (B,), generator=gen).to(device)
+    poss = torch.randint(0, wl.n_item, (B,), generator=gen).to(device)
+    negs = torch.randint(0, wl.n_item, (B,), generator=gen).to(device)
+    timer = LayerTimer()
+    model.layer_hook = timer
+    opt = dg.optim.Adam(model, lr=1e-3, weight_decay=0)  # DiffGraph-Rec/main.py:117-119
+    seed_vec = torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=device)
+    return wl, graphs, model, timer, lambda: training_step(model, opt, ancs, poss, negs, seed_vec)
+
+
+def other_workload(workload: str, device, iters: int = 10):
+    """The per-layer roofline rows of another Rec workload, measured the same way as the headline's (eager training
+    steps behind a device-side spin, then inference-mode propagation): {"frac": mean over the forward launches of the
+    training step, "per_layer": [...]}."""
+    wl, graphs, model, timer, step = rec_step(workload, device)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    rows = time_layers(model, timer, step, iters, graphs)
+    fwd = [r for r in rows if r["mode"].startswith("training")]
+    ms = float(np.mean([r["ms_per_launch"] for r in fwd]))
+    return {"workload": f"{workload}: {wl.note}", "bytes_per_launch": fwd[0]["bytes_algorithmic"], "ms_per_launch": ms,
+            "frac": fwd[0]["bytes_algorithmic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_inference": float(np.mean([r["frac"] for r in rows if r["mode"] == "inference"])), "per_layer": rows}
+
+
+def cpu_step_baseline(wl, model, budget_s: float = 20.0):
+    """The oracle's whole training step minus Adam -- rec_cal_loss + backward under torch autograd, the work `value`
+    divides by -- on the host cores: directed edges of the step's 2 L propagation passes per second."""
+    from oracle import ref_cpu as O
+    from diffgraph_amd import data as dgdata
+    T = torch.from_numpy
+    mk = lambda ui: tuple(T(a.astype(np.int64)) for a in dgdata.bipartite_edges(ui[0], ui[1], wl.n_user))
+    target, behs = mk(wl.target), [mk(b) for b in wl.behaviours]
+    gen = torch.Generator().manual_seed(1)
+    B = model.args.batch
+    ancs, poss, negs = (torch.randint(0, k, (B,), generator=gen) for k in (wl.n_user, wl.n_item, wl.n_item))
+    ts_u, ts_i = (torch.randint(0, model.args.steps, (k,), generator=gen) for k in (wl.n_user, wl.n_item))
+    noise_u, noise_i = torch.randn(wl.n_user, 64, generator=gen), torch.randn(wl.n_item, 64, generator=gen)
+
+    def weights(dn):
+        g = lambda p: p.detach().cpu().clone().requires_grad_(True)
+        return O.DenoiseWeights(g(dn.emb_layer.weight), g(dn.emb_layer.bias), g(dn.in_layers[0].weight), g(dn.in_layers[0].bias),
+                                g(dn.out_layers[0].weight), g(dn.out_layers[0].bias))
+    a = model.args
+    tab = O.DiffusionTables(a.noise_scale, a.noise_min, a.noise_max, a.steps)
+    edges_per_step = 2 * model.n_layers * sum(2 * len(ui[0]) for ui in [wl.target] + wl.behaviours)
+    t0, n = time.perf_counter(), 0
+    while True:
+        ue = T(dgdata.xavier_uniform(wl.n_user, 64, seed=0)).requires_grad_(True)
+        ie = T(dgdata.xavier_uniform(wl.n_item, 64, seed=1)).requires_grad_(True)
+        loss = O.rec_cal_loss(tab, weights(model.usr_denoiser), weights(model.item_denoiser), target, behs, ue, ie, ancs, poss, negs,
+                              ts_u, noise_u, ts_i, noise_i, float(a.batch), float(a.reg))[0]
+        loss.backward()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"step_value": edges_per_step * n / el, "step_sample": f"{n} x (rec_cal_loss + backward) of the {wl.name} workload under torch "
+            f"autograd, no optimizer step, {el:.1f} s"}
 
 
 def build_rec(workload: str, device):
@@ -304,26 +419,8 @@ def main():
             res = bench_next.bench_metapath(args.steps, args.warmup, not args.no_cpu_baseline)
         print(json.dumps(res))
         return
-    wl, graphs, model = build_rec(workload, device)
-    n = wl.n
-    gen = torch.Generator().manual_seed(1)
+    wl, graphs, model, timer, step = rec_step(workload, device)
     B = model.args.batch
-    # (uniform random triples; `--workload epoch_tmall` runs whole epochs over the real, popularity-skewed pairs)
-    ancs = torch.randint(0, wl.n_user, (B,), generator=gen).to(device)
-    poss = torch.randint(0, wl.n_item, (B,), generator=gen).to(device)
-    negs = torch.randint(0, wl.n_item, (B,), generator=gen).to(device)
-
-    timer = LayerTimer()
-    model.layer_hook = timer
-    import diffgraph_amd as dg
-    opt = dg.optim.Adam(model, lr=1e-3, weight_decay=0)  # DiffGraph-Rec/main.py:117-119
-    from diffgraph_amd.train import training_step
-    seed_vec = torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=device)
-
-    def step():
-        # one training step as Coach.trainEpoch runs it (DiffGraph-Rec/main.py:114-128): cal_loss (timesteps
-        # and noise drawn inside training_losses2, Model.py:352-353), backward, Adam
-        return training_step(model, opt, ancs, poss, negs, seed_vec)   # float64[4]: loss, bprLoss, regLoss, diff_loss
 
     if args.no_graph:
         run = step
@@ -350,41 +447,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    # Kernel-level timing for the roofline, in this same process: HIP events around each fused layer launch of (a) the
-    # step just timed, launched eagerly (events cannot be read back from inside a replayed graph; the kernels and
-    # their arguments are the same), and (b) the inference-mode propagation (HGDM.predict's), back to back.
-    # The timed step runs its short side launches (random draws, time-bias tables, buffer clearing) BESIDE the first
-    # layer launch; here they stay in line on the one stream, so that an interval holds the layer kernels alone.
-    timer.enabled = True
-    model.side_overlap = False
-    for _ in range(max(args.steps // 2, 10)):
-        torch.cuda._sleep(10_000_000)   # the GPU spins ~5 ms while the host queues the step: launches then run back to back,
-        step()                          # and an interval holds kernel time, not the host's launch latency
-    torch.cuda.synchronize()
-    model.side_overlap = True
-    train_layers = timer.by_key()
-    timer.records = []
-    with torch.no_grad():
-        for _ in range(max(args.steps // 2, 10)):
-            model.propagate(model.embedding_table)
-    torch.cuda.synchronize()
-    timer.enabled = False
-    infer_layers = timer.by_key()
-
+    per_layer = time_layers(model, timer, step, max(args.steps // 2, 10), graphs)
     L = model.n_layers
     nnz = [g.num_edges() for g in graphs]
     edges_per_step = 2 * L * sum(nnz)  # L forward + L backward (transposed) propagation launches per graph
-
-    def rows(d, mode):
-        out = []
-        for (layer, writes), v in sorted(d.items()):
-            algo, comp = v["bytes"]
-            sec = v["ms"] * 1e-3
-            out.append({"mode": mode, "layer": layer + 1, "writes": writes, "launches": v["n"], "ms_per_launch": v["ms"],
-                        "bytes_algorithmic": algo, "bytes_compulsory": comp, "frac": algo / sec / 1e9 / HBM_PEAK_GBS,
-                        "frac_compulsory": comp / sec / 1e9 / HBM_PEAK_GBS, "spmm_edges_per_s": sum(nnz) / sec})
-        return out
-    per_layer = rows(train_layers, "training step (forward)") + rows(infer_layers, "inference")
     fwd = [r for r in per_layer if r["mode"].startswith("training")]
     layer_bytes_algo = fwd[0]["bytes_algorithmic"]
     layer_ms = float(np.mean([r["ms_per_launch"] for r in fwd]))          # the forward layer launches of the timed step
@@ -401,23 +467,43 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{workload}: {wl.note}", "n_user": wl.n_user, "n_item": wl.n_item,
                    "graphs": len(graphs), "directed_edges_per_graph": nnz, "layers": L,
-                   "step": "one training step: HGDM.cal_loss (propagation, q_sample + denoiser + SNR loss, BPR) "
-                           "+ backward + Adam; eval-mode dropout (the reference's mode from its second epoch on); `value` "
-                           "divides the edges of the step's 2 L propagation launches per graph by the WHOLE step's time",
+                   "step": f"`value` is the {workload} workload on one GPU: one training step = HGDM.cal_loss (propagation, "
+                           "q_sample + denoiser + SNR loss, BPR) + backward + Adam; eval-mode dropout (the reference's mode from "
+                           "its second epoch on); the edges of the step's 2 L propagation passes per graph divided by the WHOLE "
+                           "step's time.  Runs with --gpus N > 1 time another experiment, the Industry forward propagation "
+                           "sharded over N ranks: compare those with `industry_1gpu_edges_per_s` here (the same forward on one "
+                           "GPU), not with `value`",
                    "spmm_only_edges_per_s": sum(nnz) / (layer_ms * 1e-3),
                    "batch": B, "loss": float(out[0].detach()), "launch": "eager" if args.no_graph else "hip-graph replay"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "gcn_layer_kernel + hub_reduce_kernel (one fused propagation layer, all graphs; mean over the "
-                               "forward layer launches of the training step, timed with nothing running beside them -- in the "
-                               "replayed step the first one shares the GPU with the step's short side launches and takes "
-                               "about 10 % longer, see the step timeline under profiles/)",
+                     "kernel": "set_layer_kernel + set_hub_kernel (one propagation layer as ONE row walk over all graphs; mean "
+                               "over the forward layer launches of the training step, timed with nothing running beside them -- "
+                               "in the replayed step the first one shares the GPU with the step's short side launches, see the "
+                               "step timeline under profiles/)",
                      "bytes_per_launch": layer_bytes_algo, "ms_per_launch": layer_ms,
                      "bytes_compulsory": comp_mean, "frac_compulsory": comp_mean / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "per_layer": per_layer},
     }
+    others = {}
+    for name in [w for w in args.other_workloads.split(",") if w]:
+        # the other configuration the propagation target is quoted on, same method, a few seconds
+        others[name] = other_workload(name, device)
+    if args.one_gpu_forward:
+        # the experiment the multi-GPU runs time (Industry forward propagation), here on this one GPU, so that a line of
+        # `--gpus N` has its one-GPU partner in the default run
+        from diffgraph_amd import dist as dgdist
+        name = args.one_gpu_forward
+        one = dgdist.bench_sharded(SimpleNamespace(workload=name, steps=10, warmup=3), 0, 1, device)
+        res["config"][f"{name}_1gpu_edges_per_s"] = one["value"]
+        res["config"][f"{name}_1gpu_ms_per_forward"] = one["ms_per_step"]
+        others[f"{name} (forward propagation, the --gpus N experiment on one GPU)"] = {
+            k: one["roofline"][k] for k in ("frac", "frac_compulsory", "bytes_per_launch", "ms_per_launch")}
+    if others:
+        res["roofline"]["other_workloads"] = others
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(wl)
+        res["cpu_baseline"].update(cpu_step_baseline(wl, model))
     print(json.dumps(res))
 
 

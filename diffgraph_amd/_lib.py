@@ -81,6 +81,7 @@ class WgradReduceTask(C.Structure):
 SIGNATURES = {
     "dg_version": (C.c_int, []),
     "dg_last_error": (C.c_char_p, []),
+    "dg_source_digest": (C.c_char_p, []),
     "dg_graph_create": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_void_p)]),
     "dg_graph_create_ex": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
@@ -114,6 +115,8 @@ SIGNATURES = {
     "dg_time_bias_tables": (C.c_int, [C.POINTER(C.POINTER(Denoiser)), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "dg_denoise_fwd": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_int32, C.c_void_p, C.c_void_p]),
+    "dg_denoise_fwd_train": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "dg_p_sample_loop": (C.c_int, [C.POINTER(Denoiser), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "dg_p_sample_loop_batched": (C.c_int, [C.POINTER(PSampleTask), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
@@ -187,6 +190,14 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # a library built from other kernel sources than the ones beside it is stale: refuse it instead of measuring or
+    # testing something else than the tree holds (sources absent, e.g. an installed copy: nothing to compare with)
+    from . import build as _build
+    if os.path.isdir(_build.CSRC) and not os.environ.get("DG_ALLOW_STALE_LIB"):
+        built, here = lib.dg_source_digest().decode(), _build.source_digest()
+        if built != here:
+            raise DiffGraphHipError(f"{LIB_PATH} was built from other kernel sources (digest {built}, the sources here have "
+                                    f"{here}): rebuild it with `python -m diffgraph_amd.build`")
     _lib = lib
     return lib
 

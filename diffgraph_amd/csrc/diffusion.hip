@@ -57,7 +57,7 @@ struct dn_task {
   // dropout between F.normalize and the first Linear (LOSS and its backward; Model.py:221-224)
   const uint8_t *keep_mask;           // [n][64], nonzero = kept; NULL: drawn from drop_seed
   const int64_t *drop_seed;           // one device word: the key of the draw
-  float drop_scale;                   // 1 / (1 - p); 0: no dropout
+  float drop_scale;                   // 1 / (1 - rate applied); 0: no dropout
   uint32_t drop_thr, drop_stream;     // kept iff the element's random byte >= drop_thr; stream = task number
   int64_t n;
   int32_t n_steps, norm, blk_begin;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch bat
     xs[1] = a * xs[1] + s * nz[1];
     if (T.x_t_out) store_tile(T.x_t_out + row * DG_D, h, valid, xs);
   }
-  if (MODE == MODE_LOSS && T.drop_scale != 0.f) {
+  if ((MODE == MODE_LOSS || MODE == MODE_FWD) && T.drop_scale != 0.f) {
     f32x16 m[2];
     drop_tile(T, row, h, valid, m);
     denoise_tile(wl, lane, h, norm, T.time_bias + t * DG_D, T.b_out, xs, out, m);
@@ -593,6 +593,26 @@ extern "C" int dg_q_sample(const float *x0, const float *noise, const int64_t *t
   return 0;
 }
 
+// Training-mode dropout of a task (dn_task::keep_mask ...): off for drop_p == 0.
+static int set_dropout(const char *who, const uint8_t *keep_mask, const int64_t *drop_seed, float drop_p, dn_task &k) {
+  if (drop_p == 0.f) return 0;
+  if (!(drop_p > 0.f && drop_p < 1.f)) return dg_fail(DG_ERR_ARG, "%s: drop_p must lie in [0,1) (got %g)", who, (double)drop_p);
+  if (!keep_mask && !drop_seed) return dg_fail(DG_ERR_ARG, "%s: dropout needs keep_mask or drop_seed", who);
+  if (keep_mask && ((uintptr_t)keep_mask & 3)) return dg_fail(DG_ERR_ARG, "%s: keep_mask must be 4-byte aligned", who);
+  k.keep_mask = keep_mask; k.drop_seed = drop_seed;
+  k.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
+  k.drop_thr = (uint32_t)lrint((double)drop_p * 256.0);
+  if (!keep_mask) {
+    // a mask drawn here has 8 random bits per element: the rate actually applied is drop_thr / 256, and the kept
+    // elements are scaled by ITS reciprocal complement, so that the expectation stays the input's (p = 0.5: exact)
+    if (k.drop_thr == 0 || k.drop_thr >= 256)
+      return dg_fail(DG_ERR_ARG, "%s: a drawn dropout mask takes rates of k/256, 0 < k < 256 (got %g); hand in a keep_mask", who,
+                     (double)drop_p);
+    k.drop_scale = 256.0f / (float)(256 - (int)k.drop_thr);
+  }
+  return 0;
+}
+
 extern "C" int dg_denoise_fwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps, const float *x,
                               const int64_t *t, int64_t n, int32_t d, float *out, void *stream) {
   int rc = check_denoiser("dg_denoise_fwd", dn, time_bias, n_steps, d);
@@ -602,6 +622,20 @@ extern "C" int dg_denoise_fwd(const dg_denoiser *dn, const float *time_bias, int
   dn_task k = {};
   k.w_in = dn->w_in; k.w_out = dn->w_out; k.b_out = dn->b_out; k.time_bias = time_bias;
   k.x = x; k.t = t; k.out = out; k.n = n; k.n_steps = n_steps; k.norm = dn->norm;
+  return launch_one<MODE_FWD>(k, (hipStream_t)stream);
+}
+
+extern "C" int dg_denoise_fwd_train(const dg_denoiser *dn, const float *time_bias, int32_t n_steps, const float *x,
+                                    const int64_t *t, int64_t n, int32_t d, const uint8_t *keep_mask,
+                                    const int64_t *drop_seed, float drop_p, float *out, void *stream) {
+  int rc = check_denoiser("dg_denoise_fwd_train", dn, time_bias, n_steps, d);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!x || !t || !out || n < 0) return dg_fail(DG_ERR_ARG, "dg_denoise_fwd_train: NULL argument");
+  dn_task k = {};
+  k.w_in = dn->w_in; k.w_out = dn->w_out; k.b_out = dn->b_out; k.time_bias = time_bias;
+  k.x = x; k.t = t; k.out = out; k.n = n; k.n_steps = n_steps; k.norm = dn->norm;
+  if ((rc = set_dropout("dg_denoise_fwd_train", keep_mask, drop_seed, drop_p, k))) return rc;
   return launch_one<MODE_FWD>(k, (hipStream_t)stream);
 }
 
@@ -705,14 +739,7 @@ int fill_loss_task(const char *who, const dg_loss_task &t, int32_t n_steps, int3
   k.w_in = t.dn->w_in; k.w_out = t.dn->w_out; k.b_out = t.dn->b_out; k.time_bias = t.time_bias;
   k.x = t.x_start; k.noise = t.noise; k.target = t.target; k.t = t.ts; k.sqrt_ac = sqrt_ac; k.sqrt_1mac = sqrt_1mac;
   k.loss_w = loss_w; k.n = t.n; k.n_steps = n_steps; k.norm = t.dn->norm;
-  if (t.drop_p != 0.f) {
-    if (!(t.drop_p > 0.f && t.drop_p < 1.f)) return dg_fail(DG_ERR_ARG, "%s: drop_p must lie in [0,1) (got %g)", who, (double)t.drop_p);
-    if (!t.keep_mask && !t.drop_seed) return dg_fail(DG_ERR_ARG, "%s: dropout needs keep_mask or drop_seed", who);
-    if (t.keep_mask && ((uintptr_t)t.keep_mask & 3)) return dg_fail(DG_ERR_ARG, "%s: keep_mask must be 4-byte aligned", who);
-    k.keep_mask = t.keep_mask; k.drop_seed = t.drop_seed;
-    k.drop_scale = 1.0f / (float)(1.0 - (double)t.drop_p);
-    k.drop_thr = (uint32_t)lrint((double)t.drop_p * 256.0);
-  }
+  if ((rc = set_dropout(who, t.keep_mask, t.drop_seed, t.drop_p, k))) return rc;
   if (!bwd) {
     if (!t.out || !t.row_loss) return dg_fail(DG_ERR_ARG, "%s: NULL output", who);
     k.out = t.out; k.row_loss = t.row_loss;
@@ -852,10 +879,12 @@ extern "C" int dg_dropout_keep_mask(const int64_t *drop_seed, int32_t task, floa
   if (!drop_seed || !mask || n < 0 || task < 0) return dg_fail(DG_ERR_ARG, "dg_dropout_keep_mask: bad argument");
   if (!(drop_p > 0.f && drop_p < 1.f)) return dg_fail(DG_ERR_ARG, "dg_dropout_keep_mask: drop_p must lie in (0,1)");
   if ((uintptr_t)mask & 3) return dg_fail(DG_ERR_ARG, "dg_dropout_keep_mask: mask must be 4-byte aligned");
+  const uint32_t thr = (uint32_t)lrint((double)drop_p * 256.0);
+  if (thr == 0 || thr >= 256) return dg_fail(DG_ERR_ARG, "dg_dropout_keep_mask: a drawn mask takes rates of k/256, 0 < k < 256 (got %g)", (double)drop_p);
   if (n == 0) return 0;
   const int64_t blocks = (2 * n + 255) / 256;
   hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, drop_seed, (uint32_t)task,
-                     (uint32_t)lrint((double)drop_p * 256.0), n, mask);
+                     thr, n, mask);
   DG_HIP(hipGetLastError());
   return 0;
 }

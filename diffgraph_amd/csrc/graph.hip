@@ -28,6 +28,14 @@ int dg_fail(int code, const char *fmt, ...) {
 extern "C" const char *dg_last_error(void) { return g_last_error.c_str(); }
 extern "C" int dg_version(void) { return 1; }
 
+#ifndef DG_SOURCE_DIGEST
+#define DG_SOURCE_DIGEST "unknown"
+#endif
+// The digest of the kernel sources this library was built from (diffgraph_amd/build.py); the marker lets a
+// build script read it out of the file without loading it.
+static const char g_source_digest[] = "DG_SOURCE_DIGEST=" DG_SOURCE_DIGEST;
+extern "C" const char *dg_source_digest(void) { return g_source_digest + sizeof("DG_SOURCE_DIGEST=") - 1; }
+
 namespace {
 
 constexpr int kHead = 13;  // neighbour ids carried in a group row's 16-word head

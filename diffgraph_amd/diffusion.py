@@ -16,7 +16,6 @@ from typing import Optional
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -59,17 +58,17 @@ class Denoise(nn.Module):
             self._params[key] = p
         return p
 
-    def forward(self, x, timesteps, mess_dropout=True):
+    def forward(self, x, timesteps, mess_dropout=True, keep_mask=None):
+        """keep_mask (uint8 / bool [n, 64]): the dropout mask to apply in train() mode instead of a fresh draw."""
         n_steps = int(getattr(self, "n_steps", 0)) or int(timesteps.max().item()) + 1
-        norm = bool(self.norm)
-        if mess_dropout and self.training and self.drop.p > 0:
-            # dropout sits between F.normalize and the first Linear (Model.py:221-224)
-            if norm:
-                x = F.normalize(x)
-            x = self.drop(x)
-            norm = False
-        p = self.params(norm)
+        p = self.params(bool(self.norm))
         p.time_bias(n_steps, refresh=True)
+        if mess_dropout and self.training and self.drop.p > 0:
+            # dropout sits between F.normalize and the first Linear (Model.py:221-224): inside the kernel, as in the
+            # loss kernels -- over the caller's mask or over one drawn from a fresh device word
+            seed = None if keep_mask is not None else torch.randint(0, 2 ** 62, (1,), device=x.device, dtype=torch.int64)
+            return ops.denoise_fwd(p, x.contiguous(), timesteps, n_steps, drop_p=float(self.drop.p), keep_mask=keep_mask,
+                                   drop_seed=seed)
         return ops.denoise_fwd(p, x.contiguous(), timesteps, n_steps)
 
 

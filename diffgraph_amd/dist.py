@@ -451,6 +451,10 @@ def bench_sharded(args, rank: int, world: int, device, backend=None) -> Optional
                                 "activation table per layer") if row_blocks else
                                ("HGDM.forward propagation, user rows sharded over the ranks, one all-gather of the "
                                 "item partial sums per layer"),
+                       "value_is": f"the {workload} forward propagation over {world} rank(s): its one-GPU partner is "
+                                   "`same_workload_1gpu_edges_per_s` of this line (measured by rank 0 in this run) or "
+                                   "`industry_1gpu_edges_per_s` of the default one-GPU run -- NOT the `value` of that run, "
+                                   "which times a Tmall training step",
                        "parallelism": f"row blocks x{world}" if row_blocks else f"user-row shards x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": "one sharded propagation layer on rank 0 (propagation kernels + "

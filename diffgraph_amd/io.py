@@ -39,21 +39,28 @@ def _to_cpu(obj):
     return obj
 
 
-def save_checkpoint(path: str, model, optimizer=None, epoch: int = 0, metrics: Optional[Dict] = None) -> None:
-    """Coach.saveModel (main.py:196-201) as tensors only: model.state_dict(), the optimiser's state (moments and
-    step counts, so training resumes where it stopped), the epoch and the metric lists."""
+def save_checkpoint(path: str, model, optimizer=None, epoch: int = 0, metrics: Optional[Dict] = None,
+                    extra: Optional[Dict] = None) -> None:
+    """Coach.saveModel (main.py:196-201) as tensors only: model.state_dict() (with the Rec model's device-side draw
+    state: seed and draws made so far), the optimiser's state (moments and step counts, so training resumes where it
+    stopped), the epoch, the metric lists and `extra` (tensors / numbers / nested dicts and lists of them: a coach's
+    random-generator states)."""
     torch.save({"model": _to_cpu(model.state_dict()), "optimizer": None if optimizer is None else _to_cpu(optimizer.state_dict()),
-                "epoch": int(epoch), "metrics": metrics or {}}, path)
+                "epoch": int(epoch), "metrics": metrics or {}, "extra": _to_cpu(extra or {})}, path)
 
 
 def load_checkpoint(path: str, model, optimizer=None) -> Dict:
     """Coach.loadModel (main.py:203-211): restores the model in place and -- unlike the reference, which starts Adam
-    afresh -- the optimiser.  Returns {'epoch': ..., 'metrics': ...}."""
+    afresh -- the optimiser.  Returns {'epoch': ..., 'metrics': ..., 'extra': ...}.  A file written before the draw
+    state was part of the model's state loads too (the draws then start over)."""
     ckp = torch.load(path, map_location="cpu", weights_only=True)
-    model.load_state_dict(ckp["model"])
+    res = model.load_state_dict(ckp["model"], strict=False)
+    bad = [k for k in list(res.missing_keys) + list(res.unexpected_keys) if k != "draw_state"]
+    if bad:
+        raise RuntimeError(f"checkpoint {path}: state_dict keys do not match the model: {bad}")
     if optimizer is not None and ckp.get("optimizer") is not None:
         optimizer.load_state_dict(ckp["optimizer"])
-    return {"epoch": ckp["epoch"], "metrics": ckp["metrics"]}
+    return {"epoch": ckp["epoch"], "metrics": ckp["metrics"], "extra": ckp.get("extra", {})}
 
 
 def save_history(path: str, metrics: Dict) -> None:

@@ -214,8 +214,9 @@ class HGDM(nn.Module):
         in_dims = out_dims[::-1]
         self.usr_denoiser = Denoise(in_dims, out_dims, args.d_emb_size, norm=args.norm).to(device)
         self.item_denoiser = Denoise(in_dims, out_dims, args.d_emb_size, norm=args.norm).to(device)
-        # {seed, draws made, dropout key, 0} of the timesteps / noise / dropout masks drawn on the device
-        self.register_buffer("draw_state", ops.new_draw_state(device), persistent=False)
+        # {seed, draws made, dropout key, 0} of the timesteps / noise / dropout masks drawn on the device; part of the
+        # state_dict, so that a resumed run goes on with the draws that follow instead of repeating the first ones
+        self.register_buffer("draw_state", ops.new_draw_state(device), persistent=True)
         self._side: Optional[torch.cuda.Stream] = None
         self._side_pending: list = []
         self._late_side: list = []

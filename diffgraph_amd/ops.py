@@ -348,11 +348,26 @@ def q_sample(x0: torch.Tensor, noise: torch.Tensor, t: torch.Tensor, sqrt_ac: to
     return out
 
 
-def denoise_fwd(dn: DenoiserParams, x: torch.Tensor, t: torch.Tensor, n_steps: int, validate: bool = True) -> torch.Tensor:
+def denoise_fwd(dn: DenoiserParams, x: torch.Tensor, t: torch.Tensor, n_steps: int, validate: bool = True, drop_p: float = 0.0,
+                keep_mask: Optional[torch.Tensor] = None, drop_seed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Denoise.forward; with drop_p > 0 the train-mode form: dropout over keep_mask (uint8 / bool [n, 64]) or over a mask
+    drawn from drop_seed (int64[1] on the GPU)."""
     _table(x, "x")
     _check_t(t, x.shape[0], n_steps, validate)
     tb = dn.time_bias(n_steps)
     out = torch.empty_like(x)
+    if drop_p > 0:
+        if keep_mask is not None:
+            if not keep_mask.is_cuda or keep_mask.dtype not in (torch.uint8, torch.bool) or tuple(keep_mask.shape) != tuple(x.shape):
+                raise DiffGraphHipError("keep_mask: expected a uint8 / bool GPU tensor of x's shape")
+            keep_mask = keep_mask.contiguous().view(torch.uint8)
+        elif drop_seed is not None:
+            _vec(drop_seed, "drop_seed", torch.int64, 1)
+        rc = _lib.load().dg_denoise_fwd_train(C.byref(dn.c), tb.data_ptr(), n_steps, x.data_ptr(), t.data_ptr(), x.shape[0], DG_D,
+                                              _ptr(keep_mask), _ptr(drop_seed), float(drop_p), out.data_ptr(),
+                                              _lib.stream_ptr(x.device))
+        _lib.check(rc, "dg_denoise_fwd_train")
+        return out
     rc = _lib.load().dg_denoise_fwd(C.byref(dn.c), tb.data_ptr(), n_steps, x.data_ptr(), t.data_ptr(), x.shape[0], DG_D,
                                     out.data_ptr(), _lib.stream_ptr(x.device))
     _lib.check(rc, "dg_denoise_fwd")

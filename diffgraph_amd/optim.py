@@ -2,9 +2,10 @@
 weight_decay=0)).
 
 The embedding table -- 16 MB of the model's 16.1 MB -- is stepped by one HIP kernel that reads the gradient as
-the tables the backward pass produced (their sum is never written); the denoiser weights go through torch's fused
-multi-tensor Adam.  state_dict() / load_state_dict() carry both, so a run can be resumed (the reference's
-loadModel re-creates Adam from scratch, main.py:205-211).
+the tables the backward pass produced (their sum is never written); the twelve denoiser tensors by one launch of
+dg_adam_multi (SmallAdam) with its step count on the device -- no torch kernel is left in a recorded step.
+state_dict() / load_state_dict() carry both, so a run can be resumed (the reference's loadModel re-creates Adam
+from scratch, main.py:205-211).
 """
 from __future__ import annotations
 
@@ -22,7 +23,7 @@ class Adam:
         self.table = model.embedding_table
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         rest = [p for p in model.parameters() if p is not self.table]
-        self.rest = torch.optim.Adam(rest, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True, capturable=True)
+        self.rest = SmallAdam(rest, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.exp_avg = torch.zeros_like(self.table)
         self.exp_avg_sq = torch.zeros_like(self.table)
         self.state = torch.zeros(4, dtype=torch.float32, device=self.table.device)
@@ -90,6 +91,7 @@ class SmallAdam:
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.state = torch.zeros(4, dtype=torch.float32, device=self.params[0].device)
+        self._live = None       # which parameters had a gradient in the first step (see step)
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self.params:
@@ -99,10 +101,19 @@ class SmallAdam:
                 p.grad.zero_()
 
     def step(self) -> None:
+        mask = tuple(p.grad is not None for p in self.params)
+        if not any(mask):
+            return
+        # ONE step count for all tensors: a tensor that joined or left between steps would get another tensor's bias
+        # correction (torch keeps a count per tensor), so the set of tensors with a gradient is fixed by the first step
+        if self._live is None:
+            self._live = mask
+        elif mask != self._live:
+            k = next(i for i, (a, b) in enumerate(zip(mask, self._live)) if a != b)
+            raise _lib.DiffGraphHipError(f"SmallAdam: parameter {k} {'has' if mask[k] else 'lacks'} a gradient, unlike in the steps "
+                                         "before: the tensors share one step count")
         live = [(p, p.grad.contiguous(), m, v) for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq) if p.grad is not None]
         n = len(live)
-        if n == 0:
-            return
         if n > 32:
             raise _lib.DiffGraphHipError("SmallAdam: at most 32 tensors per step (one launch, one step count)")
         arrs = [(C.c_void_p * n)(*[t[k].data_ptr() for t in live]) for k in range(4)]
@@ -117,6 +128,18 @@ class SmallAdam:
                 "hyper": {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}}
 
     def load_state_dict(self, sd: Dict) -> None:
+        if "param_groups" in sd:      # a torch.optim.Adam state_dict (checkpoints written before this class stepped the tensors)
+            st = sd["state"]
+            steps = {float(v["step"]) for v in st.values()}
+            if len(st) not in (0, len(self.params)) or len(steps) > 1:
+                raise _lib.DiffGraphHipError("SmallAdam: a torch Adam state loads only with one step count over all tensors")
+            with torch.no_grad():
+                for k in st:
+                    self.exp_avg[int(k)].copy_(st[k]["exp_avg"])
+                    self.exp_avg_sq[int(k)].copy_(st[k]["exp_avg_sq"])
+                self.state.zero_()
+                self.state[0] = steps.pop() if steps else 0.0
+            return
         with torch.no_grad():
             for dst, src in zip(self.exp_avg + self.exp_avg_sq, list(sd["exp_avg"]) + list(sd["exp_avg_sq"])):
                 dst.copy_(src)

@@ -95,7 +95,7 @@ class Coach:
     def _snapshot(self):
         o = self.opt
         return ([p.detach().clone() for p in self.model.parameters()], o.exp_avg.clone(), o.exp_avg_sq.clone(), o.state.clone(),
-                {p: {k: v.clone() for k, v in st.items()} for p, st in o.rest.state.items()}, self._sums.clone(),
+                ([t.clone() for t in o.rest.exp_avg + o.rest.exp_avg_sq], o.rest.state.clone()), self._sums.clone(),
                 self._batch_no.clone(), None if self._draw_no is None else self._draw_no.clone(), self.model.draw_state.clone())
 
     def _restore(self, snap) -> None:
@@ -109,9 +109,9 @@ class Coach:
             self.model.draw_state.copy_(draw_state)
             if draw_no is not None:
                 self._draw_no.copy_(draw_no)
-            for p, st in o.rest.state.items():      # moments the warm-up steps created start from zero
-                for k, t in st.items():
-                    t.copy_(rest[p][k]) if p in rest else t.zero_()
+            for t, q in zip(o.rest.exp_avg + o.rest.exp_avg_sq, rest[0]):
+                t.copy_(q)
+            o.rest.state.copy_(rest[1])
 
     def _capture(self, size: int):
         """Records one step over a batch of `size` pairs as a HIP graph.  The recording takes its triples out of the
@@ -196,10 +196,13 @@ class Coach:
 
     # ------------------------------------------------------------------ main.py:196-211 (state dicts, no pickled modules)
     def saveModel(self, path: str) -> None:
-        io.save_checkpoint(path, self.model, self.opt)
+        # (the shuffle's generator too: the model's own draw state travels in its state_dict)
+        io.save_checkpoint(path, self.model, self.opt, extra={"shuffle_generator": self._gen.get_state()})
 
     def loadModel(self, path: str) -> None:
         if self.model is None:
             self.prepareModel()
-        io.load_checkpoint(path, self.model, self.opt)
+        info = io.load_checkpoint(path, self.model, self.opt)
+        if "shuffle_generator" in info["extra"]:
+            self._gen.set_state(info["extra"]["shuffle_generator"])
         self._graphs = {}

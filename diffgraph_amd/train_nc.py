@@ -172,10 +172,21 @@ class NCCoach:
                 "micro": max(hist["test_micro"])}
 
     def saveModel(self, path: str) -> None:
-        io.save_checkpoint(path, self.model, self.opt)
+        # with the generators of the steps' draws and of the batch order: a resumed run draws what comes next
+        st = self._order.bit_generator.state
+        io.save_checkpoint(path, self.model, self.opt, extra={
+            "draw_generator": self._gen.get_state(),
+            "order_generator": {"bit_generator": st["bit_generator"], "state": str(st["state"]["state"]), "inc": str(st["state"]["inc"]),
+                                "has_uint32": int(st["has_uint32"]), "uinteger": int(st["uinteger"])}})
 
     def loadModel(self, path: str) -> None:
         if self.model is None:
             self.prepareModel()
-        io.load_checkpoint(path, self.model, self.opt)
+        extra = io.load_checkpoint(path, self.model, self.opt)["extra"]
+        if "draw_generator" in extra:
+            self._gen.set_state(extra["draw_generator"])
+        if "order_generator" in extra:
+            o = extra["order_generator"]
+            self._order.bit_generator.state = {"bit_generator": o["bit_generator"], "state": {"state": int(o["state"]), "inc": int(o["inc"])},
+                                               "has_uint32": int(o["has_uint32"]), "uinteger": int(o["uinteger"])}
         self._graphs = {}

@@ -35,6 +35,8 @@ extern "C" {
 #define DG_MAX_TASKS 8          /* graphs per batched layer launch */
 
 int dg_version(void);
+/* Digest (16 hex digits) of the kernel sources the library was built from, "unknown" for a build without one. */
+const char *dg_source_digest(void);
 const char *dg_last_error(void);
 
 /* ------------------------------------------------------------------------------------
@@ -290,6 +292,13 @@ int dg_time_bias_tables(const dg_denoiser *const *dns, float *const *tables, int
 int dg_denoise_fwd(const dg_denoiser *dn, const float *time_bias, int32_t n_steps, const float *x,
                    const int64_t *t, int64_t n, int32_t d, float *out, void *stream);
 
+/* The same in train() mode with mess_dropout=True (Model.py:221-224): nn.Dropout(drop_p) between F.normalize and the
+ * first Linear, over the caller's keep_mask (uint8 [n][64], nonzero = kept) or a mask drawn from the device word
+ * *drop_seed (task number 0 of dg_dropout_keep_mask) -- see dg_loss_task for the two forms.  drop_p = 0: dg_denoise_fwd. */
+int dg_denoise_fwd_train(const dg_denoiser *dn, const float *time_bias, int32_t n_steps, const float *x,
+                         const int64_t *t, int64_t n, int32_t d, const uint8_t *keep_mask,
+                         const int64_t *drop_seed, float drop_p, float *out, void *stream);
+
 /* a8: GaussianDiffusion.p_sample(model, x_start, steps=0) reverse loop
  * (DiffGraph-Rec/Model.py:287-300 with p_mean_variance :314-325): for i = n_steps-1..0:
  *     x <- coef1[i]*Denoise(x, i) + coef2[i]*x
@@ -359,11 +368,13 @@ typedef struct dg_loss_task {
   float *d_x_start, *d_target, *dout_tot, *hid, *dpre, *xn;
   /* Training-mode dropout of Denoise.forward (nn.Dropout between F.normalize and the first Linear,
    * DiffGraph-Rec/Model.py:193,221-224; active while the module is in train() mode, i.e. the reference's
-   * first epoch, main.py:144).  drop_p = 0: off.  Otherwise an element is multiplied by 1/(1-drop_p) if kept
-   * and by 0 if dropped; kept = keep_mask[row][col] != 0 when keep_mask (uint8 [n][64]) is given, else a draw
-   * of probability 1 - round(256 drop_p)/256 from a counter-based generator keyed by the DEVICE word
-   * *drop_seed, the task's position in the call and the row -- the backward call redraws the same mask from
-   * the same word; dg_dropout_keep_mask writes it out. */
+   * first epoch, main.py:144).  drop_p = 0: off.  With keep_mask (uint8 [n][64]): an element is multiplied by
+   * 1/(1-drop_p) where keep_mask[row][col] != 0 and by 0 elsewhere (torch's arithmetic on a mask torch drew).
+   * Without: the mask is drawn here, 8 random bits per element, from a counter-based generator keyed by the
+   * DEVICE word *drop_seed, the task's position in the call and the row -- so the rate applied is
+   * q = round(256 drop_p)/256 (argument error unless 0 < q < 1) and kept elements are multiplied by 1/(1-q),
+   * which keeps the expectation (drop_p = 0.5, the reference's rate: q = drop_p).  The backward call redraws the
+   * same mask from the same word; dg_dropout_keep_mask writes it out. */
   const uint8_t *keep_mask;
   const int64_t *drop_seed;
   float drop_p;

@@ -20,7 +20,7 @@ def _run(*args, env=None):
 
 
 def test_training_step_line_on_the_tiny_workload():
-    r = _run("--workload", "tiny", "--steps", "3", "--warmup", "2")
+    r = _run("--workload", "tiny", "--steps", "3", "--warmup", "2", "--other-workloads", "tiny", "--one-gpu-forward", "tiny")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in r, k
@@ -37,10 +37,17 @@ def test_training_step_line_on_the_tiny_workload():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in r["cpu_baseline"], k
     assert r["cpu_baseline"]["kind"] == "port" and r["config"]["loss"] == r["config"]["loss"]   # a number, not NaN
+    # a like-for-like CPU figure for `value` (the whole step), the other workloads' layer fractions, and the one-GPU
+    # partner of the multi-GPU experiment -- so that two lines of different --gpus can be compared without a third run
+    assert r["cpu_baseline"]["step_value"] > 0 and "step_sample" in r["cpu_baseline"]
+    ow = r["roofline"]["other_workloads"]
+    assert 0 < ow["tiny"]["frac"] and {p["layer"] for p in ow["tiny"]["per_layer"]} == {1, 2}
+    assert r["config"]["tiny_1gpu_edges_per_s"] > 0 and "value` is the tiny workload" in r["config"]["step"]
 
 
 def test_eager_step_gives_the_same_kind_of_line():
-    r = _run("--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline")
+    r = _run("--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--other-workloads", "",
+             "--one-gpu-forward", "")
     assert r["config"]["launch"] == "eager" and "cpu_baseline" not in r and r["value"] > 0
 
 
@@ -51,6 +58,7 @@ def test_gpus_flag_starts_its_own_ranks():
     r = _run("--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1", env={"DG_DIST_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0
     assert r["config"]["speedup_over_1gpu"] > 0 and "x2" in r["config"]["parallelism"]
+    assert r["config"]["same_workload_1gpu_edges_per_s"] > 0 and "one-GPU partner" in r["config"]["value_is"]
 
 
 @pytest.mark.parametrize("flags, launch", [((), "hip-graph replay"), (("--no-graph",), "eager")])
@@ -59,4 +67,7 @@ def test_nc_training_step_leg(flags, launch):
     by default; the same kind of line, finite losses."""
     r = _run("--workload", "nc_train_dblp", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", *flags)
     assert r["config"]["launch"] == launch and r["unit"] == "edges/s" and r["value"] > 0 and r["n_gpus"] == 1
-    assert all(x == x and abs(x) < 1e3 for x in r["config"]["loss"]) and r["roofline"]["bound"] == "hbm"
+    assert all(x == x and abs(x) < 1e3 for x in r["config"]["loss"])
+    # the as-coded DBLP graphs (3 x the 11 113-edge co-author graph) are sparse: no bitmap graph, nothing for the matrix cores
+    rf = r["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and "hbm_secondary" in rf and rf["bitmap_graphs"] in (0, 2)

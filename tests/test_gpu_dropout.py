@@ -8,7 +8,8 @@ import torch
 
 import diffgraph_amd as dg
 from diffgraph_amd import data as dgdata, ops
-from tests.helpers import GRAD_TOL, REC_TABLE, assert_close_to_max, assert_rows_close, load, tiny_fixture
+from oracle import ref_cpu as O
+from tests.helpers import GRAD_TOL, REC_TABLE, assert_close_to_max, assert_rows_close, load, tiny_fixture, weights_from
 from tests.test_gpu_parity import DEV, dev, rec_model, T
 
 pytestmark = pytest.mark.gpu
@@ -132,6 +133,17 @@ def test_mask_drawn_in_the_kernel_equals_the_mask_supplied():
     xn = bwd_a[5]
     unit = torch.nn.functional.normalize(sa[ts][:, None] * x0 + sb[ts][:, None] * noise)
     assert_rows_close(xn, unit * m * 2.0, what="xn after dropout")
+    # a rate that 8 random bits cannot hit: the drawn mask drops round(256 p)/256 of the elements and scales the kept ones
+    # by the reciprocal of what is left of THAT rate, so the expectation stays the input's
+    sp01 = [ops.LossSpan(sp.dn, sp.begin, sp.n, 0.1) for sp in spans]
+    xn01 = ops.diffusion_loss_bwd_spans(sp01, target, x0, noise, ts, sa, sb, lw, g_row, g_out, drop_seed=seed)[5]
+    m01 = torch.cat([ops.dropout_keep_mask(seed, 0, 0.1, n_u), ops.dropout_keep_mask(seed, 1, 0.1, n_i)]).float()
+    assert abs(float(m01.mean()) - (1 - 26 / 256)) < 0.005
+    assert_rows_close(xn01, unit * m01 * (256.0 / 230.0), what="xn after dropout at p = 0.1")
+    assert abs(float(m01.mean()) * 256.0 / 230.0 - 1.0) < 0.005      # E[mask * scale] = 1
+    for bad in (0.001, 0.999):
+        with pytest.raises(dg.DiffGraphHipError):
+            ops.dropout_keep_mask(seed, 0, bad, n_u)
     # eval-mode call (drop_p = 0) ignores seed and mask
     plain = [ops.LossSpan(sp.dn, sp.begin, sp.n) for sp in spans]
     rl_c, _ = ops.diffusion_loss_fwd_spans(plain, target, x0, noise, ts, sa, sb, lw)
@@ -194,3 +206,32 @@ def test_model_in_train_mode_draws_fresh_masks():
     assert torch.isfinite(a).all() and not torch.equal(a, b)     # two draws
     assert torch.equal(c, d)                                     # no dropout: deterministic
     np.testing.assert_allclose(c.cpu().numpy(), fx["cl_losses"], rtol=1e-5)
+
+
+def test_denoise_forward_in_train_mode_runs_the_dropout_inside_the_kernel():
+    """Denoise.forward(x, t, mess_dropout=True) in train() mode (Model.py:221-224: normalize, Dropout(0.5), first
+    Linear): over a given keep mask it equals the oracle's forward of normalize(x) * mask * 2 without its own
+    normalisation; without a mask it draws one (two calls differ, eval mode and mess_dropout=False do not drop)."""
+    import torch.nn.functional as F
+    fx, *_ = tiny_fixture()
+    w = weights_from(fx, "usr_")
+    dn = dg.Denoise([64, 64], [64, 64], 8, norm=True).to(DEV)
+    with torch.no_grad():
+        for prm, val in zip((dn.emb_layer.weight, dn.emb_layer.bias, dn.in_layers[0].weight, dn.in_layers[0].bias,
+                             dn.out_layers[0].weight, dn.out_layers[0].bias), (w.w_emb, w.b_emb, w.w_in, w.b_in, w.w_out, w.b_out)):
+            prm.copy_(val)
+    dn.n_steps = 200
+    gen = torch.Generator().manual_seed(11)
+    for n in (1, 33, 500):
+        x, t = torch.randn(n, 64, generator=gen), torch.randint(0, 200, (n,), generator=gen)
+        mask = torch.rand(n, 64, generator=gen) >= 0.5
+        dn.train()
+        got = dn(dev(x), dev(t), True, keep_mask=dev(mask))
+        want = O.denoise_forward(w, F.normalize(x) * mask.float() * 2.0, t, norm=False)
+        assert_rows_close(got, want, what=f"train-mode Denoise.forward, n={n}")
+        plain = O.denoise_forward(w, x, t, norm=True)
+        assert_rows_close(dn(dev(x), dev(t), False), plain, what="mess_dropout=False")
+        a, b = dn(dev(x), dev(t)), dn(dev(x), dev(t))
+        assert torch.isfinite(a).all() and not torch.equal(a, b)
+        dn.eval()
+        assert_rows_close(dn(dev(x), dev(t)), plain, what="eval mode")

@@ -609,6 +609,29 @@ def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
     train(m2, o2, 2)
     for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(p1, p2), n1
+    # the device-side draw state (seed, draws made) is part of the model's state: steps that draw their own timesteps
+    # and noise go on after a restore with the draws that follow, not with the first ones again
+    draw_args = args[:3]
+
+    def train_drawn(m, o, n):
+        out = []
+        for _ in range(n):
+            loss = m.cal_loss(*draw_args)[0]
+            o.zero_grad(set_to_none=True)
+            loss.backward()
+            o.step()
+            out.append(float(loss))
+        return out
+
+    train_drawn(m1, o1, 2)
+    assert int(m1.draw_state[1]) == 2
+    dg.io.save_checkpoint(path, m1, o1)
+    want = train_drawn(m1, o1, 2)
+    m3 = rec_model(wl, fx)
+    o3 = dg.optim.Adam(m3, lr=1e-2)
+    dg.io.load_checkpoint(path, m3, o3)
+    assert int(m3.draw_state[0]) == int(m1.draw_state[0]) and int(m3.draw_state[1]) == 2
+    assert train_drawn(m3, o3, 2) == want and want[0] != want[1]
     # interaction matrices round-trip through the pickle-free file
     import scipy.sparse as sp
     mat = sp.coo_matrix((np.arange(1, len(wl.target[0]) + 1, dtype=np.float32), (wl.target[0], wl.target[1])), shape=(nu, ni))
@@ -1069,7 +1092,62 @@ def test_tmall_size_forward_and_cal_loss_against_oracle():
                        ts_i, noise_i, batch, reg)
     np.testing.assert_allclose([float(v.detach()) for v in (loss, bpr, regl, diff)], [float(v.detach()) for v in o], rtol=1e-5)
     o[0].backward()
-    assert_rows_close(m.embedding_table.grad, torch.cat([ue_.grad, ie_.grad]), rtol=5e-5, what="tmall d e0")
+    # The yardstick for every row of d e0 is the oracle in fp64 -- differentiated along the LeakyReLU branches the KERNELS
+    # took.  A hot item's gradient row adds a few thousand terms of both signs: the fp32 oracle's own running sum is
+    # then 2e-5 of the row scale off, so it cannot pin 1e-5; and LeakyReLU has a kink at 0: where a pre-activation lies
+    # within rounding of 0, an fp64 evaluation may stand on the other side of it and differentiate another branch -- a
+    # difference of the FUNCTION, not of the arithmetic (the fp64 and fp32 oracles' own gradients differ by up to 0.2 of
+    # the row scale in the rows that neighbour such an entry).  So: (1) the fp64 oracle's forward is its own, its
+    # backward takes the derivative 1 or `slope` by the sign of the kernels' activations: every row agrees at 1e-5;
+    # (2) the entries where kernels and fp64 oracle stand on different sides are counted and shown to be roundings of
+    # zero; (3) against the fp32 oracle's autograd the rows beyond 1e-5 are counted (< 5 %) and lie within 5e-5.
+    with torch.no_grad():
+        saved = m._propagate(m.embedding_table.detach(), keep=True)[2]
+    branches = iter([(saved[g][l] > 0).cpu() for g in range(4) for l in range(2)])     # the oracle's call order
+    flips = []
+
+    class _LeakyAlong(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, slope, pos):
+            ctx.save_for_backward(pos)
+            ctx.slope = slope
+            return torch.where(x > 0, x, x * slope)
+
+        @staticmethod
+        def backward(ctx, g):
+            return torch.where(ctx.saved_tensors[0], g, g * ctx.slope), None, None
+
+    def leaky_along(x, slope):
+        pos = next(branches)
+        xd = x.detach()
+        other = pos != (xd > 0)
+        rows = other.any(dim=1)
+        flips.append((int(other.sum()), float((xd.abs() * other).max()), float(xd.abs().max(dim=1).values[rows].min()) if rows.any() else 0.0))
+        return _LeakyAlong.apply(x, slope, pos)
+
+    ue2, ie2 = ue.double().requires_grad_(True), ie.double().requires_grad_(True)
+    from unittest import mock
+    with mock.patch.object(O.F, "leaky_relu", leaky_along):
+        o2 = O.rec_cal_loss(O.DiffusionTables(**REC_TABLE), _oracle_weights(m.usr_denoiser).to(torch.float64),
+                            _oracle_weights(m.item_denoiser).to(torch.float64), target, behs, ue2, ie2, ancs, poss, negs, ts_u,
+                            noise_u.double(), ts_i, noise_i.double(), batch, reg)
+        o2[0].backward()
+    assert len(flips) == 8 and abs(float(o2[0]) - float(o[0])) <= 1e-5 * abs(float(o[0]))
+    n_flips = sum(f[0] for f in flips)
+    assert n_flips < 1e-5 * 8 * (nu + ni) * 64, flips           # a handful of the 32 M activations ...
+    for cnt, worst, row_scale in flips:                       # ... each a rounding of zero against its row
+        assert cnt == 0 or worst <= 1e-5 * row_scale, flips
+    got = m.embedding_table.grad
+    assert_rows_close(got, torch.cat([ue2.grad, ie2.grad]),
+                      what=f"tmall d e0 vs the fp64 oracle along the kernels' LeakyReLU branches ({n_flips} entries on the other side)")
+    own = torch.cat([ue_.grad, ie_.grad])
+    err = (got.cpu().double() - own.double()).abs()
+    scale = own.double().abs().max(dim=1, keepdim=True).values
+    beyond = (err > 1e-5 * scale + 1e-30).any(dim=1)
+    assert int(beyond.sum()) < 0.05 * (nu + ni), int(beyond.sum())
+    assert_rows_close(got[beyond.to(got.device)], own[beyond], rtol=5e-5,
+                      what=f"tmall d e0 vs the fp32 oracle's autograd: the {int(beyond.sum())} rows beyond 1e-5")
+    assert_rows_close(got[(~beyond).to(got.device)], own[~beyond], what="tmall d e0 vs the fp32 oracle's autograd: all other rows")
     for pre, dn, w in (("usr_", m.usr_denoiser, wu), ("item_", m.item_denoiser, wi)):
         got = {"w_emb": dn.emb_layer.weight.grad, "b_emb": dn.emb_layer.bias.grad, "w_in": dn.in_layers[0].weight.grad,
                "b_in": dn.in_layers[0].bias.grad, "w_out": dn.out_layers[0].weight.grad, "b_out": dn.out_layers[0].bias.grad}

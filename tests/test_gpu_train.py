@@ -84,11 +84,8 @@ def _fixed_draws(coach, n_steps, seed, keep):
 
 
 def _optimizer_state(o):
-    out = [o.exp_avg, o.exp_avg_sq, o.state]
-    for prm in o.rest.param_groups[0]["params"]:        # the optimizer's own order (the same for every model instance)
-        st = o.rest.state[prm]
-        out += [st[k] for k in sorted(st) if torch.is_tensor(st[k])]
-    return out
+    # the table's moments and step count, then the denoiser tensors' (in parameter order, the same for every model instance)
+    return [o.exp_avg, o.exp_avg_sq, o.state] + o.rest.exp_avg + o.rest.exp_avg_sq + [o.rest.state]
 
 
 @pytest.mark.parametrize("draws", ["given", "drawn"])
@@ -349,3 +346,7 @@ def test_nc_coach_run_and_checkpoint(tmp_path):
     d.loadModel(path)
     a, b = c.testEpoch(0)[1], d.testEpoch(0)[1]
     assert torch.equal(a["logits"], b["logits"]) and a["macro"] == b["macro"]
+    # the generators of the draws and of the batch order travel too: the next epoch is the same, number for number
+    assert c.trainEpoch(0) == d.trainEpoch(0)
+    for p, q in zip(c.model.parameters(), d.model.parameters()):
+        assert torch.equal(p, q)

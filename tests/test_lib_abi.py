@@ -63,3 +63,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.DiffGraphHipError):
         _lib.load()
+
+
+def test_library_carries_the_digest_of_its_sources_and_a_stale_one_is_refused(monkeypatch):
+    """The library names the kernel sources it was built from (dg_source_digest, compiled in by diffgraph_amd.build);
+    _lib.load() refuses a library whose digest is not the one of the sources on disk."""
+    from diffgraph_amd import build
+    lib = _lib.load()
+    assert lib.dg_source_digest().decode() == build.source_digest() == build.library_digest()
+    assert not build.needs_build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "source_digest", lambda: "0123456789abcdef")      # as if a source file had changed
+    with pytest.raises(_lib.DiffGraphHipError, match="other kernel sources"):
+        _lib.load()
+    assert build.needs_build()

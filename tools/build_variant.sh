@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds a variant of libdiffgraph_hip.so with extra compiler flags for spmm.hip and graph.hip into
-# scratch/libdg_<tag>.so (for A/B timing on the GPU box: copy it over diffgraph_amd/libdiffgraph_hip.so in that run only).
+# scratch/libdg_<tag>.so (for A/B timing on the GPU box: copy it over diffgraph_amd/libdiffgraph_hip.so in that run only, and
+# run with DG_ALLOW_STALE_LIB=1: a variant carries no source digest, so diffgraph_amd._lib would refuse it).
 #   tools/build_variant.sh <tag> [flags...]
 set -e
 cd "$(dirname "$0")/.."
@@ -12,6 +13,6 @@ for s in spmm graph; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function "$@" -c $C/$s.hip -o scratch/${s}_$tag.o
 done
 objs=""
-for s in diffusion wgrad losshead eval sampling spgemm optim linear; do objs="$objs $C/$s.o"; done
+for s in fused diffusion wgrad losshead eval sampling spgemm optim linear; do objs="$objs $C/$s.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/libdg_$tag.so scratch/spmm_$tag.o scratch/graph_$tag.o $objs
 echo scratch/libdg_$tag.so
