@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 struct dg_graphset {
@@ -41,6 +42,8 @@ struct dg_graphset {
   int32_t *hub_desc = nullptr; // [n_hub][8]: cut row, first slab row of graphs 0..3, last slab row + 1, 0, 0
   int32_t *seg_desc = nullptr, *gseg_desc = nullptr;  // as dg_csr's
   int32_t n_hub = 0, n_seg = 0, n_seg_slots = 0, n_gseg_slots = 0;
+  int32_t n_rec = 0;           // head records (group rows, plus skipped slots that pad the block order)
+  int32_t side_split = 0;      // > 0: bipartite at this row, and the two sides' work is dealt to separate XCDs
   float *slab = nullptr;
 };
 
@@ -65,7 +68,7 @@ struct set_dev {
   float *sum_first, *sum_rest;
   const float *e_saved;  // backward: the layer's forward activations, stacked
   const float *d_first, *d_rest;  // backward: gradients wrt the two sums
-  int32_t n, n_graphs, n_hub, n_seg_slots, n_gseg_slots;
+  int32_t n, n_graphs, n_hub, n_seg_slots, n_gseg_slots, n_rec;
   float slope;
 };
 
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void set_layer_kernel(const set_dev T) {
     }
   } else {
     const int k = (lb - nb_seg - nb_gseg) * 16 + wave * 4 + q;
-    if (k < T.n) {
+    if (k < T.n_rec) {
       const int hv = T.head[(size_t)k * 16 + l];
       const float hs = SCALE ? T.head_scale[(size_t)k * 16 + l] : 0.f;
       const int total = bcast16<12>(hv), row = bcast16<13>(hv), tail = bcast16<15>(hv);
@@ -328,6 +331,7 @@ int fill(const dg_graphset *s, int mode, set_dev &t) {
   t.e_out = nullptr; t.e0 = nullptr; t.sum_first = t.sum_rest = nullptr;
   t.e_saved = nullptr; t.d_first = t.d_rest = nullptr;
   t.n = s->n; t.n_graphs = s->n_graphs; t.n_hub = s->n_hub; t.n_seg_slots = s->n_seg_slots; t.n_gseg_slots = s->n_gseg_slots;
+  t.n_rec = s->n_rec;
   t.slope = 0.f;
   int device = 0;
   DG_HIP(hipGetDevice(&device));
@@ -338,7 +342,7 @@ int fill(const dg_graphset *s, int mode, set_dev &t) {
 
 template <int MODE>
 int launch(const dg_graphset *s, const set_dev &t, hipStream_t stream) {
-  const int blocks = (s->n_seg_slots >> 2) + (s->n_gseg_slots >> 4) + ((s->n + 15) >> 4);
+  const int blocks = (s->n_seg_slots >> 2) + (s->n_gseg_slots >> 4) + ((s->n_rec + 15) >> 4);
   hipLaunchKernelGGL(set_layer_kernel<MODE>, dim3(blocks), dim3(256), 0, stream, t);
   if (s->n_hub > 0) hipLaunchKernelGGL(set_hub_kernel<MODE>, dim3((s->n_hub + 3) >> 2), dim3(256), 0, stream, t);
   DG_HIP(hipGetLastError());
@@ -419,24 +423,46 @@ extern "C" int dg_graphset_create(dg_graph *const *graphs, int32_t n_graphs, int
       norms[(size_t)r * 8 + 4 + g] = dsrc[g][r];
     }
   }
+  // Bipartite in every graph at the same row (makeBiAdj's block form, users then items)?  Then the two sides' rows
+  // gather from disjoint halves of the tables, and (DG_SET_SPLIT=1) their work is dealt to separate XCDs -- workgroup
+  // b runs on XCD b mod 8 --: rows below the split to XCDs 0..3, the others to XCDs 4..7, so that an XCD's 4 MB of L2
+  // serves one half of the tables only.  Both sides hold the same number of edge ends, so the halves weigh the same.
+  int32_t split = n;
+  for (int g = 0; g < n_graphs; ++g)
+    for (int32_t r = 0; r < n; ++r)
+      if (rowptr[g][r + 1] > rowptr[g][r] && colidx[g][rowptr[g][r]] > r) split = std::min(split, colidx[g][rowptr[g][r]]);
+  if (split >= n) split = 0;
+  for (int g = 0; g < n_graphs && split > 0; ++g)
+    for (int32_t r = 0; r < n; ++r) {
+      if (rowptr[g][r + 1] == rowptr[g][r]) continue;
+      const int32_t lo = colidx[g][rowptr[g][r]], hi = colidx[g][rowptr[g][r + 1] - 1];
+      if (r < split ? lo < split : hi >= split) { split = 0; break; }
+    }
+  const char *split_env = getenv("DG_SET_SPLIT");
+  const bool side_split = split > 0 && split_env && atoi(split_env) > 0;
   // cut rows: pieces by graph, by range of the stacked ids, by length
   std::vector<int32_t> hub_rows;
   for (int32_t r = 0; r < n; ++r)
     if (quads[r] > quad_max) hub_rows.push_back(r);
   std::stable_sort(hub_rows.begin(), hub_rows.end(), [&](int32_t a, int32_t b) { return quads[a] > quads[b]; });
-  int32_t limit[kRuns + 1];
-  {
+  // range limits of the runs: all 8 runs over all cut rows -- or, split by side, runs 0..3 over the cut rows below
+  // the split and runs 4..7 over the others
+  int32_t limit[2][kRuns + 1];
+  for (int side = 0; side < 2; ++side) {
     std::vector<int32_t> ids;
-    for (int32_t r : hub_rows)
+    for (int32_t r : hub_rows) {
+      if (side_split ? (r < split) != (side == 0) : side == 1) continue;
       for (int64_t p = base[r]; p < base[r + 1]; ++p)
         if (col_stacked[(size_t)p] >= 0) ids.push_back(col_stacked[(size_t)p]);
-    limit[0] = 0;
-    limit[kRuns] = INT32_MAX;
-    for (int x = 1; x < kRuns; ++x) {
-      if (ids.empty()) { limit[x] = INT32_MAX; continue; }
-      const size_t at = ids.size() * (size_t)x / kRuns;
+    }
+    const int runs = side_split ? kRuns / 2 : kRuns;
+    limit[side][0] = 0;
+    for (int x = 1; x <= kRuns; ++x) limit[side][x] = INT32_MAX;
+    for (int x = 1; x < runs; ++x) {
+      if (ids.empty()) continue;
+      const size_t at = ids.size() * (size_t)x / runs;
       std::nth_element(ids.begin(), ids.begin() + at, ids.end());
-      limit[x] = ids[at];
+      limit[side][x] = ids[at];
     }
   }
   struct Piece { int32_t begin, end, slab; };
@@ -446,6 +472,8 @@ extern "C" int dg_graphset_create(dg_graph *const *graphs, int32_t n_graphs, int
   for (int32_t r : hub_rows) {
     int32_t first[kMaxSetGraphs + 1];
     int64_t p0 = base[r];
+    const int side = side_split && r >= split ? 1 : 0;
+    const int runs = side_split ? kRuns / 2 : kRuns, run0 = side * (kRuns / 2);
     for (int g = 0; g < kMaxSetGraphs; ++g) {
       first[g] = n_seg;
       if (g >= n_graphs) continue;
@@ -453,14 +481,14 @@ extern "C" int dg_graphset_create(dg_graph *const *graphs, int32_t n_graphs, int
       const int32_t *cs = col_stacked.data();
       int32_t p = (int32_t)p0;
       const int32_t e = p + d;
-      for (int x = 0; x < kRuns && p < e; ++x) {
-        const int32_t pe = x + 1 == kRuns ? e : (int32_t)(std::lower_bound(cs + p, cs + e, limit[x + 1]) - cs);
+      for (int x = 0; x < runs && p < e; ++x) {
+        const int32_t pe = x + 1 == runs ? e : (int32_t)(std::lower_bound(cs + p, cs + e, limit[side][x + 1]) - cs);
         const int32_t len = pe - p;
         if (len <= 0) continue;
         const int32_t parts = (len + seg_len - 1) / seg_len;
         for (int32_t k = 0; k < parts; ++k) {
           const int32_t b0 = p + (int32_t)((int64_t)len * k / parts), b1 = p + (int32_t)((int64_t)len * (k + 1) / parts);
-          (b1 - b0 > kGroupPiece ? wave_pieces : group_pieces)[x].push_back({b0, b1, n_seg++});
+          (b1 - b0 > kGroupPiece ? wave_pieces : group_pieces)[run0 + x].push_back({b0, b1, n_seg++});
         }
         p = pe;
       }
@@ -498,11 +526,26 @@ extern "C" int dg_graphset_create(dg_graph *const *graphs, int32_t n_graphs, int
     return qn > 24 ? 0 : qn > 16 ? 1 : qn > 11 ? 2 : qn > 7 ? 3 : qn > 3 ? 4 : qn > 0 ? 5 : 6;
   };
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return list_class(a) < list_class(b); });
-  std::vector<int32_t> head_plain((size_t)n * 16, -1), head_stacked((size_t)n * 16, -1);
-  std::vector<float> head_scale((size_t)n * 16, 0.f);
-  for (int32_t k = 0; k < n; ++k) {
+  if (side_split) {
+    // blocks of 16 records in rounds of 8: the first four of a round take rows below the split, the other four rows
+    // above it (slots left over when a side runs out stay empty: -1 = skip)
+    std::vector<int32_t> sides[2];
+    for (int32_t r : order)
+      if (quads[r] <= quad_max) sides[r < split ? 0 : 1].push_back(r);
+    const size_t rounds = std::max((sides[0].size() + 63) / 64, (sides[1].size() + 63) / 64);
+    std::vector<int32_t> dealt(rounds * 128, -1);
+    for (int side = 0; side < 2; ++side)
+      for (size_t i = 0; i < sides[side].size(); ++i)
+        dealt[(i / 64) * 128 + side * 64 + i % 64] = sides[side][i];
+    order.swap(dealt);
+  }
+  const int32_t n_rec = (int32_t)order.size();
+  std::vector<int32_t> head_plain((size_t)n_rec * 16, -1), head_stacked((size_t)n_rec * 16, -1);
+  std::vector<float> head_scale((size_t)n_rec * 16, 0.f);
+  for (int32_t k = 0; k < n_rec; ++k) {
     const int32_t r = order[k];
     int32_t *hp = &head_plain[(size_t)k * 16], *hk = &head_stacked[(size_t)k * 16];
+    if (r < 0) continue;                // an empty slot: word 12 stays -1
     hp[13] = hk[13] = r;
     if (quads[r] > quad_max) continue;  // word 12 stays -1
     float *hs = &head_scale[(size_t)k * 16];
@@ -525,6 +568,7 @@ extern "C" int dg_graphset_create(dg_graph *const *graphs, int32_t n_graphs, int
   dg_graphset *s = new dg_graphset();
   s->n = n; s->n_graphs = n_graphs; s->nnz = nnz; s->device = device; s->quad_max = quad_max; s->seg_len = seg_len;
   s->n_hub = (int32_t)hub_rows.size(); s->n_seg = n_seg; s->n_seg_slots = n_seg_slots; s->n_gseg_slots = n_gseg_slots;
+  s->n_rec = n_rec; s->side_split = side_split ? split : 0;
   hipError_t e = upload(col_plain, &s->col_plain);
   if (e == hipSuccess) e = upload(col_stacked, &s->col_stacked);
   if (e == hipSuccess) e = upload(colscale, &s->colscale);
@@ -556,7 +600,7 @@ extern "C" void dg_graphset_destroy(dg_graphset *s) {
 extern "C" int dg_graphset_counts(const dg_graphset *s, int32_t *counts_host) {
   if (!s || !counts_host) return dg_fail(DG_ERR_ARG, "dg_graphset_counts: NULL argument");
   counts_host[0] = s->n; counts_host[1] = s->n_graphs; counts_host[2] = s->n_hub; counts_host[3] = s->n_seg;
-  counts_host[4] = s->quad_max; counts_host[5] = s->seg_len;
+  counts_host[4] = s->quad_max; counts_host[5] = s->seg_len; counts_host[6] = s->side_split;
   return 0;
 }
 

@@ -170,9 +170,9 @@ class GraphSet:
         return list(self._nnz)
 
     def counts(self) -> dict:
-        c = (C.c_int32 * 6)()
+        c = (C.c_int32 * 7)()
         _lib.check(_lib.load().dg_graphset_counts(self.handle, c), "dg_graphset_counts")
-        return {"n": c[0], "graphs": c[1], "n_hub": c[2], "n_seg": c[3], "quad_max": c[4], "seg_len": c[5]}
+        return {"n": c[0], "graphs": c[1], "n_hub": c[2], "n_seg": c[3], "quad_max": c[4], "seg_len": c[5], "side_split": c[6]}
 
     def close(self) -> None:
         if self._h is not None:

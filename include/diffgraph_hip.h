@@ -248,7 +248,7 @@ typedef struct dg_graphset dg_graphset;
 int dg_graphset_create(dg_graph *const *graphs, int32_t n_graphs, int32_t group_max, int32_t seg_len,
                        dg_graphset **out);
 void dg_graphset_destroy(dg_graphset *set);
-/* counts_host[6] = {nodes, graphs, cut rows, slab rows, quads a group row may hold, seg_len} */
+/* counts_host[7] = {nodes, graphs, cut rows, slab rows, quads a group row may hold, seg_len, side split (0: none)} */
 int dg_graphset_counts(const dg_graphset *set, int32_t *counts_host);
 int dg_set_layer_first(dg_graphset *set, const float *x, float *e_out, float slope, int32_t d, void *stream);
 int dg_set_layer_last(dg_graphset *set, const float *x, const float *e0, float *sum_first, float *sum_rest,

@@ -80,6 +80,7 @@ with torch.no_grad():
     for fuse, kn in [(False, (0, 0))] + [(True, k) for k in knobs]:
         model.fuse_graphs = fuse
         if fuse:
+            os.environ["DG_SET_SPLIT"] = str(kn[2]) if len(kn) > 2 else "0"      # third knob: sides dealt to separate XCDs
             model._gset, model._gset_graphs = dg.GraphSet(graphs, group_max=kn[0], seg_len=kn[1]), list(graphs)
             what = f"graph set group_max={kn[0]} seg_len={kn[1]} {model._gset.counts()}"
         else:
@@ -88,8 +89,9 @@ with torch.no_grad():
             l0, l1, whole = layers(keep)
             print(f"{name} {what}: keep={keep}: layer1 {l0:.1f} us  layer2 {l1:.1f} us  forward {whole:.1f} us  "
                   f"frac {algo / ((l0 + l1) / 2 * 1e-6) / 8e12:.3f}", flush=True)
-for fuse in (False, True):
+for fuse, split in ((False, 0), (True, 0), (True, 1)):
     model.fuse_graphs = fuse
     if fuse:
+        os.environ["DG_SET_SPLIT"] = str(split)
         model._gset = None
-    print(f"{name} {'graph set' if fuse else 'task per graph'}: forward(keep) + backward {backward_time():.1f} us", flush=True)
+    print(f"{name} {'graph set' if fuse else 'task per graph'} split={split}: forward(keep) + backward {backward_time():.1f} us", flush=True)
