@@ -45,11 +45,20 @@ def timed(fn, reps=50, warm=10):
     return float(np.median(ts))
 
 
+FLUSH = None
+if os.environ.get("DG_BENCH_FLUSH_MB"):      # a table of that size rewritten before every pass: the passes start with cold caches
+    FLUSH = torch.empty(int(os.environ["DG_BENCH_FLUSH_MB"]) << 18, dtype=torch.float32, device=dev)
+
+
 def layers(keep):
     """median us of layer 0 / layer 1 launches (all kernels of the layer) and of the whole forward"""
     global ev
     model.layer_hook = None
-    run = lambda: model._propagate(model.embedding_table.detach(), keep=keep)
+
+    def run():
+        if FLUSH is not None:
+            FLUSH.add_(1.0)
+        return model._propagate(model.embedding_table.detach(), keep=keep)
     whole = timed(run)
     ev = []
     model.layer_hook = hook
