@@ -157,7 +157,20 @@ __device__ __forceinline__ void drop_tile(const dn_task &T, int64_t row, int h, 
     for (int e = 0; e < 4; ++e) m[c >> 2][4 * (c & 3) + e] = ((w[c] >> (8 * e)) & 0xffu) >= T.drop_thr ? T.drop_scale : 0.f;
 }
 
+// tanh on the hardware's exp2 and reciprocal (1 ulp each): 1 - 2 / (e^{2|x|} + 1) from |x| = 1/4 on, the odd series
+// below (where the first form would cancel); within 5e-7 of tanhf, relative, at a fifth of its instructions.  For
+// the single-step kernels, whose wavefronts wait on it; the reverse loop keeps tanhf (its time is the matrix
+// instructions' chain: the short form measured no faster there).
+__device__ __forceinline__ float tanh_short(float x) {
+  const float ax = fabsf(x), x2 = ax * ax;
+  const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);      // e^{2|x|}
+  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float small = ax * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+  return copysignf(ax < 0.25f ? small : big, x);
+}
+
 // One Denoise.forward on the 32-row tile held in xs: F.normalize, (dropout,) in-layer + tanh, out-layer.
+template <bool SHORT_TANH = false>
 __device__ __forceinline__ void denoise_tile(const f32x4 *__restrict__ wl, int lane, int h, bool norm,
                                              const float *__restrict__ tb_row, const float *__restrict__ b_out,
                                              const f32x16 (&xs)[2], f32x16 (&out)[2], const f32x16 *drop = nullptr) {
@@ -183,7 +196,7 @@ __device__ __forceinline__ void denoise_tile(const f32x4 *__restrict__ wl, int l
 #pragma unroll
   for (int tau = 0; tau < 2; ++tau)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hid[tau][r] = tanhf(hid[tau][r]);
+    for (int r = 0; r < 16; ++r) hid[tau][r] = SHORT_TANH ? tanh_short(hid[tau][r]) : tanhf(hid[tau][r]);
   load_tile(b_out, h, true, out);
   contract64(wl + 2 * 2 * 4 * 64, lane, hid, out);
 }
@@ -197,22 +210,22 @@ __global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch bat
   for (int k = 1; k < batch.n_tasks; ++k)
     if (b >= batch.t[k].blk_begin) ti_ = k;
   const dn_task &T = batch.t[ti_];
-
-  for (int idx = threadIdx.x; idx < 2 * 2 * 2 * 4 * 64; idx += blockDim.x) {
-    const int ln = idx & 63, rq = (idx >> 6) & 3, ti = (idx >> 8) & 1, to = (idx >> 9) & 1, m = idx >> 10;
-    const int row = 32 * to + (ln & 31), col = 32 * ti + 8 * rq + 4 * (ln >> 5);
-    const float *src = m == 0 ? T.w_in + row * 72 + col : T.w_out + row * 64 + col;
-    wl[idx] = *reinterpret_cast<const f32x4 *>(src);
-  }
-  __syncthreads();
-
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int64_t row = ((int64_t)(b - T.blk_begin) * kWavesPerBlock + wave) * kRowsPerWave + j;
   const bool valid = row < T.n;
   const bool norm = T.norm != 0;
 
+  // the row tile is asked for before the weight images are staged: its way from HBM overlaps the staging
   f32x16 xs[2], out[2];
   load_tile(T.x + row * DG_D, h, valid, xs);
+
+  for (int idx = threadIdx.x; idx < 2 * 2 * 2 * 4 * 64; idx += blockDim.x) {
+    const int ln = idx & 63, rq = (idx >> 6) & 3, ti = (idx >> 8) & 1, to = (idx >> 9) & 1, m = idx >> 10;
+    const int wrow = 32 * to + (ln & 31), col = 32 * ti + 8 * rq + 4 * (ln >> 5);
+    const float *src = m == 0 ? T.w_in + wrow * 72 + col : T.w_out + wrow * 64 + col;
+    wl[idx] = *reinterpret_cast<const f32x4 *>(src);
+  }
+  __syncthreads();
 
   if (MODE == MODE_PSAMPLE) {
     for (int step = T.n_steps - 1; step >= 0; --step) {
@@ -242,9 +255,9 @@ __global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch bat
   if ((MODE == MODE_LOSS || MODE == MODE_FWD) && T.drop_scale != 0.f) {
     f32x16 m[2];
     drop_tile(T, row, h, valid, m);
-    denoise_tile(wl, lane, h, norm, T.time_bias + t * DG_D, T.b_out, xs, out, m);
+    denoise_tile<true>(wl, lane, h, norm, T.time_bias + t * DG_D, T.b_out, xs, out, m);
   } else {
-    denoise_tile(wl, lane, h, norm, T.time_bias + t * DG_D, T.b_out, xs, out);
+    denoise_tile<true>(wl, lane, h, norm, T.time_bias + t * DG_D, T.b_out, xs, out);
   }
   store_tile(T.out + row * DG_D, h, valid, out);
   if (MODE == MODE_LOSS) {  // mean_flat((target-out)^2) * (SNR(t-1)-SNR(t)) (Model.py:360-364)
@@ -275,6 +288,16 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
   for (int k = 1; k < batch.n_tasks; ++k)
     if (b >= batch.t[k].blk_begin) ti_ = k;
   const dn_task &T = batch.t[ti_];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int64_t row = ((int64_t)(b - T.blk_begin) * kWavesPerBlock + wave) * kRowsPerWave + j;
+  const bool valid = row < T.n;
+  const int64_t ro = row * DG_D;
+  int t = 0;
+  if (valid) t = min(max((int)T.t[row], 0), T.n_steps - 1);
+  // the row tiles are asked for before the weight images are staged: their way from HBM overlaps the staging
+  f32x16 xs[2], nz[2];
+  load_tile(T.x + ro, h, valid, xs);
+  if (T.sqrt_ac != nullptr) load_tile(T.noise + ro, h, valid, nz);
   for (int idx = threadIdx.x; idx < 4 * 2 * 2 * 4 * 64; idx += blockDim.x) {
     const int ln = idx & 63, rq = (idx >> 6) & 3, ti = (idx >> 8) & 1, to = (idx >> 9) & 1, m = idx >> 10;
     const int row = 32 * to + (ln & 31), col = 32 * ti + 8 * rq + 4 * (ln >> 5);
@@ -289,19 +312,8 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
     wl[idx] = v;
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int64_t row = ((int64_t)(b - T.blk_begin) * kWavesPerBlock + wave) * kRowsPerWave + j;
-  const bool valid = row < T.n;
-  const int64_t ro = row * DG_D;
-  int t = 0;
-  if (valid) t = min(max((int)T.t[row], 0), T.n_steps - 1);
-
-  f32x16 xs[2];
-  load_tile(T.x + ro, h, valid, xs);
   float a_t = 1.0f;
   if (T.sqrt_ac != nullptr) {
-    f32x16 nz[2];
-    load_tile(T.noise + ro, h, valid, nz);
     a_t = T.sqrt_ac[t];
     const float s_t = T.sqrt_1mac[t];
     xs[0] = a_t * xs[0] + s_t * nz[0];
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
 #pragma unroll
   for (int tau = 0; tau < 2; ++tau)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hid[tau][r] = tanhf(hid[tau][r]);
+    for (int r = 0; r < 16; ++r) hid[tau][r] = tanh_short(hid[tau][r]);   // (the forward kernel's form: the same bits)
   if (!fused) store_tile(T.hid + ro, h, valid, hid);
   load_tile(T.b_out, h, true, out);
   contract64(wl + 1 * 1024, lane, hid, out);

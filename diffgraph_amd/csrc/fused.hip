@@ -644,7 +644,7 @@ extern "C" int dg_set_layer_bwd_mid(dg_graphset *set, const float *w_in, const f
   int rc = check_d("dg_set_layer_bwd_mid", set, d);
   if (rc) return rc;
   if (!w_in || !e_saved || !d_first || !d_rest || !w_out) return dg_fail(DG_ERR_ARG, "dg_set_layer_bwd_mid: NULL argument");
-  if (w_out == w_in) return dg_fail(DG_ERR_ARG, "dg_set_layer_bwd_mid: w_out must not alias w_in");
+  if (w_out == w_in) return dg_fail(DG_ERR_ARG, "dg_set_layer_bwd_mid: w_out must not alias w_in (e_saved it may: a row is read, then written, by the same lanes)");
   set_dev t;
   if ((rc = fill(set, M_BWD_MID, t))) return rc;
   t.x = w_in; t.e_saved = e_saved; t.d_first = d_first; t.d_rest = d_rest; t.e_out = w_out; t.slope = slope;

@@ -239,6 +239,7 @@ int dg_sum_tables(const float *const *in_host, int32_t n_in, float *out, int64_t
  *   dg_set_layer_bwd_top:  w_out[g] = dZ_2 of graph g from e_saved[g] = the last call's e_out   (no gather)
  *   dg_set_layer_bwd_mid:  w_out[g] = dZ_1 of graph g from w_in = the top step's w_out (gathered) and
  *                          e_saved[g] = the first call's e_out
+ * In both backward calls w_out may be e_saved itself (the result written over the activations just consumed).
  * The graphs must outlive nothing: the set copies what it needs.  Calls on one set share its slab: serialise them
  * on one stream.
  * ---------------------------------------------------------------------------------- */
