@@ -100,6 +100,7 @@ SIGNATURES = {
     "dg_gcn_partial_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "dg_gcn_partial_finalize_batched": (C.c_int, [C.POINTER(FinalizeTask), C.c_int32, C.c_int32, C.c_void_p]),
+    "dg_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "dg_gcn_layer_bwd": (C.c_int, [C.POINTER(BwdTask), C.c_int32, C.c_int32, C.c_void_p]),
     "dg_sum_tables": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dg_graphset_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "dg_set_layer_last": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int32, C.c_void_p]),
     "dg_set_layer_bwd_top": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int32, C.c_void_p]),
     "dg_set_layer_bwd_mid": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int32, C.c_void_p]),
+    "dg_set_layer_bwd_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dg_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                               C.c_int32, C.c_void_p, C.c_void_p]),
     "dg_time_bias_table": (C.c_int, [C.POINTER(Denoiser), C.c_int32, C.c_void_p, C.c_void_p]),

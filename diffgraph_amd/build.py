@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffgraph_hip.so")
-SOURCES = ["graph.hip", "spmm.hip", "fused.hip", "diffusion.hip", "wgrad.hip", "losshead.hip", "eval.hip", "sampling.hip", "spgemm.hip", "optim.hip", "linear.hip"]
+SOURCES = ["graph.hip", "spmm.hip", "fused.hip", "diffusion.hip", "wgrad.hip", "losshead.hip", "eval.hip", "sampling.hip", "spgemm.hip", "optim.hip", "linear.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "dg_internal.h"), os.path.join(CSRC, "dg_gather.h"), os.path.join(CSRC, "dg_philox.h"), os.path.join(CSRC, "dg_wgrad.h"), os.path.join(HERE, "..", "include", "diffgraph_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -72,7 +72,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

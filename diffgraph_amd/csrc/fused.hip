@@ -54,7 +54,7 @@ constexpr int kHeadSlots = 12;
 constexpr int kGroupPiece = 32;
 constexpr int kRuns = 8;
 
-enum { M_FIRST = 0, M_LAST = 1, M_BWD_MID = 2, M_BWD_TOP = 3 };
+enum { M_FIRST = 0, M_LAST = 1, M_BWD_MID = 2, M_BWD_TOP = 3, M_BWD_LAST = 4 };
 
 struct set_dev {
   const int32_t *col, *head, *hub_desc, *seg_desc, *gseg_desc;
@@ -88,7 +88,7 @@ __device__ __forceinline__ void load_set_ctx(const set_dev &T, int row, int l, s
   c.a = c.b = z;
 #pragma unroll
   for (int g = 0; g < kMaxSetGraphs; ++g) c.own[g] = z;
-  if (MODE == M_FIRST) return;
+  if (MODE == M_FIRST || MODE == M_BWD_LAST) return;
   const float *own = MODE == M_LAST ? T.x : T.e_saved;
   if (MODE == M_LAST) {
     c.a = load_stream(T.e0, o);
@@ -160,6 +160,15 @@ __device__ __forceinline__ void set_epilogue_one(const set_dev &T, size_t o, con
 template <int MODE>
 __device__ __forceinline__ void set_epilogue(const set_dev &T, int row, int l, const set_ctx &c, const f32x4 (&sums)[4]) {
   const size_t o = (size_t)row * (DG_D / 4) + l;
+  if (MODE == M_BWD_LAST) {
+    // the last backward step is linear: d e0 gets sum_g dinv_g[row] * (sum over N_g(row) of dZ_1 of graph g), one table
+    f32x4 g0 = sums[0] * bcast16f<4>(c.sc);
+    g0 += sums[1] * bcast16f<5>(c.sc);
+    if (T.n_graphs > 2) g0 += sums[2] * bcast16f<6>(c.sc);
+    if (T.n_graphs > 3) g0 += sums[3] * bcast16f<7>(c.sc);
+    store_stream(T.sum_first, o, g0);
+    return;
+  }
   f32x4 S0, S1, S2, S3;
   S0 = S1 = S2 = S3 = f32x4{0.f, 0.f, 0.f, 0.f};
   set_epilogue_one<MODE, 0>(T, o, c, sums[0], S0);
@@ -649,4 +658,14 @@ extern "C" int dg_set_layer_bwd_mid(dg_graphset *set, const float *w_in, const f
   if ((rc = fill(set, M_BWD_MID, t))) return rc;
   t.x = w_in; t.e_saved = e_saved; t.d_first = d_first; t.d_rest = d_rest; t.e_out = w_out; t.slope = slope;
   return launch<M_BWD_MID>(set, t, (hipStream_t)stream);
+}
+
+extern "C" int dg_set_layer_bwd_last(dg_graphset *set, const float *w_in, float *g_out, int32_t d, void *stream) {
+  int rc = check_d("dg_set_layer_bwd_last", set, d);
+  if (rc) return rc;
+  if (!w_in || !g_out) return dg_fail(DG_ERR_ARG, "dg_set_layer_bwd_last: NULL argument");
+  set_dev t;
+  if ((rc = fill(set, M_BWD_LAST, t))) return rc;
+  t.x = w_in; t.sum_first = g_out; t.slope = 1.0f;
+  return launch<M_BWD_LAST>(set, t, (hipStream_t)stream);
 }

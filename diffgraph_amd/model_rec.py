@@ -94,8 +94,13 @@ class _PropagateFn(torch.autograd.Function):
                                          DG_BWD_SAVED_PRESCALED if l < L else 0, slope))
                 w[g] = out
             ops.gcn_layer_bwd_batched(tasks)
-        merged = model.merged_last_step()
-        if merged is not None:
+        merged = None if ctx.gset is not None else model.merged_last_step()
+        if ctx.gset is not None:
+            # the last step over the set as well: the lists BWD_MID has just walked, one output table
+            g0 = torch.empty_like(ref)
+            ops.set_layer_bwd_last(ctx.gset, stack, g0)
+            w = [g0]
+        elif merged is not None:
             # G0 = sum_g A_g^T dZ_g as ONE table from one launch (no per-graph tables to write and add up later)
             g0 = torch.empty_like(ref)
             ops.gcn_layer_batched([ops.LayerTask(merged, stack.view(-1, ref.shape[1]), g0, None, None, 0, 1.0)])

@@ -280,6 +280,15 @@ def set_layer_bwd_mid(gset: GraphSet, w_in: torch.Tensor, e_saved: torch.Tensor,
     _lib.check(rc, "dg_set_layer_bwd_mid")
 
 
+def set_layer_bwd_last(gset: GraphSet, w_in: torch.Tensor, g_out: torch.Tensor) -> None:
+    """The last backward step over the set: what reaches the layer-0 table through all graphs' propagation, as one table
+    (the step is linear: no activation or normalisation between the graphs' terms)."""
+    _stacked(w_in, "w_in", gset)
+    _table(g_out, "g_out", gset.num_nodes())
+    rc = _lib.load().dg_set_layer_bwd_last(gset.handle, w_in.data_ptr(), g_out.data_ptr(), DG_D, _lib.stream_ptr(g_out.device))
+    _lib.check(rc, "dg_set_layer_bwd_last")
+
+
 # --------------------------------------------------------------------------------------
 # diffusion
 # --------------------------------------------------------------------------------------

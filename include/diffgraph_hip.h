@@ -184,6 +184,14 @@ typedef struct dg_finalize_task {
 
 int dg_gcn_partial_finalize_batched(const dg_finalize_task *tasks, int32_t n_tasks, int32_t d, void *stream);
 
+/* The exchange between the two halves of a row-sharded layer, for callers with an RCCL communicator of their own: one
+ * ncclAllGather of `rows_per_rank` rows of 64 floats from every rank into `full` ([ranks][rows_per_rank][64], rank
+ * order -- the layout dg_gcn_partial_finalize reads with part_stride_rows = rows_per_rank).  comm: an ncclComm_t
+ * passed as void*.  RCCL is looked up when first needed (in the process, else librccl.so): the library does not link
+ * against it.  No counterpart in the reference, which runs on one device (DiffGraph_NC/script.sh:1 exports three GPUs
+ * and uses one); diffgraph_amd.dist makes the same exchange through torch.distributed. */
+int dg_allgather_rows(void *comm, const float *local, float *full, int64_t rows_per_rank, int32_t d, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * a11: backward of one fused propagation layer, batched over graphs.  Replaces what
  * autograd records for DGLLayer.forward + F.normalize + the layer sum
@@ -239,7 +247,9 @@ int dg_sum_tables(const float *const *in_host, int32_t n_in, float *out, int64_t
  *   dg_set_layer_bwd_top:  w_out[g] = dZ_2 of graph g from e_saved[g] = the last call's e_out   (no gather)
  *   dg_set_layer_bwd_mid:  w_out[g] = dZ_1 of graph g from w_in = the top step's w_out (gathered) and
  *                          e_saved[g] = the first call's e_out
- * In both backward calls w_out may be e_saved itself (the result written over the activations just consumed).
+ *   dg_set_layer_bwd_last: g_out[i] = sum_g dinv_g[i] * sum_{j in N_g(i)} w_in[g][j]   (w_in = the mid step's w_out): the
+ *                          gradient that reaches the layer-0 table through the propagation, over all graphs, ONE table
+ * In the top and mid calls w_out may be e_saved itself (the result written over the activations just consumed).
  * The graphs must outlive nothing: the set copies what it needs.  Calls on one set share its slab: serialise them
  * on one stream.
  * ---------------------------------------------------------------------------------- */
@@ -258,6 +268,7 @@ int dg_set_layer_bwd_top(dg_graphset *set, const float *e_saved, const float *d_
                          float *w_out, float slope, int32_t d, void *stream);
 int dg_set_layer_bwd_mid(dg_graphset *set, const float *w_in, const float *e_saved, const float *d_first,
                          const float *d_rest, float *w_out, float slope, int32_t d, void *stream);
+int dg_set_layer_bwd_last(dg_graphset *set, const float *w_in, float *g_out, int32_t d, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * a6: q_sample.  Replaces GaussianDiffusion.q_sample + _extract_into_tensor

@@ -1407,6 +1407,7 @@ def test_merged_last_backward_step_equals_the_per_graph_steps():
         m = rec_model(wl, fx)
         m.set_embeddings(dev(fx["user_emb"]), dev(fx["item_emb"]))
         m.merge_last_step = merge
+        m.fuse_graphs = False      # (the task-per-graph path: the walk over the graph set has a last step of its own)
         gen = torch.Generator().manual_seed(3)
         ru, ri = torch.randn(wl.n_user, 64, generator=gen), torch.randn(wl.n_item, 64, generator=gen)
         tu, ti, hu, hi = m.forward()

@@ -43,6 +43,13 @@ def test_argument_errors_are_reported_not_launched():
     assert lib.dg_q_sample(None, None, None, None, None, 200, 4, 128, None, None) == -2
     assert lib.dg_gcn_layer_fwd(None, 0, 64, None) < 0
     assert lib.dg_sum_tables(None, 0, None, 0, None) < 0
+    # the collective entry point checks its arguments before it looks for RCCL
+    assert lib.dg_allgather_rows(None, None, None, 8, 32, None) == -2
+    assert lib.dg_allgather_rows(None, None, None, 8, 64, None) == -1 and b"comm is NULL" in lib.dg_last_error()
+    fake = C.c_void_p(1)
+    assert lib.dg_allgather_rows(fake, None, None, -1, 64, None) == -1 and b"negative" in lib.dg_last_error()
+    assert lib.dg_allgather_rows(fake, None, None, 0, 64, None) == 0            # nothing to move
+    assert lib.dg_allgather_rows(fake, None, None, 8, 64, None) == -1 and b"NULL buffer" in lib.dg_last_error()
 
 
 def test_synthetic_workloads_have_the_published_shapes():
