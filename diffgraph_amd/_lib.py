@@ -172,6 +172,7 @@ SIGNATURES = {
     "dg_adam_prepare": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "dg_adam_multi": (C.c_int, [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_int64), C.c_int32, C.c_void_p] + [C.c_float] * 5
                       + [C.c_void_p]),
+    "dg_clear": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dg_rec_head_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 10),
 }
 

@@ -318,3 +318,13 @@ extern "C" int dg_rec_head_bwd(const float *ui, const float *out_u, const float 
   DG_HIP(hipGetLastError());
   return 0;
 }
+
+// The zeroed buffer dg_rec_head_bwd starts from (autograd's zero-initialised gradient tables of the three batch gathers,
+// DiffGraph-Rec/Model.py:101-104), cleared by the runtime's memset on the caller's stream -- recorded into a HIP graph
+// it is a memset node, not a kernel.
+extern "C" int dg_clear(void *dst, size_t bytes, void *stream) {
+  if (!dst && bytes) return dg_fail(DG_ERR_ARG, "dg_clear: NULL buffer");
+  if (bytes == 0) return 0;
+  DG_HIP(hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream));
+  return 0;
+}

@@ -741,7 +741,8 @@ def rec_head_bwd_buffer(n: int, device, clear: bool = True) -> torch.Tensor:
 
 
 def clear_rec_head_bwd_buffer(buf: torch.Tensor, n: int) -> None:
-    buf[: 2 * n * DG_D * 4 + 16 * n].zero_()
+    rc = _lib.load().dg_clear(buf.data_ptr(), 2 * n * DG_D * 4 + 16 * n, _lib.stream_ptr(buf.device))
+    _lib.check(rc, "dg_clear")
 
 
 def rec_head_bwd(ui, out_u, out_i, ancs, poss, negs, n_user: int, batch_div: float, reg: float, ent_f, g, full: bool = False,

@@ -501,6 +501,10 @@ int dg_rec_head_fwd(const float *ui, const float *out_u, const float *out_i, con
 int dg_rec_head_reduce(const float *entries_f, const double *entries_d, int32_t n_batch, double batch_div,
                        double reg_coef, double *results, void *stream);
 
+/* Clears `bytes` bytes at dst on `stream` (hipMemsetAsync): the zero state dg_rec_head_bwd's buffer has to be handed
+ * over in -- the zero-initialised gradient tables autograd creates for the batch gathers of DiffGraph-Rec/Model.py:101-104. */
+int dg_clear(void *dst, size_t bytes, void *stream);
+
 /* Backward of dg_rec_head_fwd.  g: DEVICE fp64[4] = dL/d{loss,bpr,reg,diff} (what autograd hands
  * back; usually {1,0,0,0}).  Writes the dense gradient tables d_ui [n_user+n_item][64],
  * d_out_u [n_user][64], d_out_i [n_item][64], d_row_loss_u fp64[n_user], d_row_loss_i fp64[n_item]:

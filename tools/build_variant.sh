@@ -13,6 +13,6 @@ for s in spmm graph; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function "$@" -c $C/$s.hip -o scratch/${s}_$tag.o
 done
 objs=""
-for s in fused diffusion wgrad losshead eval sampling spgemm optim linear; do objs="$objs $C/$s.o"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/libdg_$tag.so scratch/spmm_$tag.o scratch/graph_$tag.o $objs
+for s in fused diffusion wgrad losshead eval sampling spgemm optim linear comm; do objs="$objs $C/$s.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/libdg_$tag.so scratch/spmm_$tag.o scratch/graph_$tag.o $objs -ldl
 echo scratch/libdg_$tag.so

@@ -33,8 +33,8 @@ for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST
   i=$((i+1))
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_layer_$i -o p -- python $R/tools/layer_bench.py tmall 0,0 > $O/pmc_layer_$i.log 2>&1
   echo "## rocprofv3 --pmc $c -- python tools/layer_bench.py tmall 0,0   (per-dispatch means; FETCH/WRITE_SIZE in KiB)" >> $O/pmc_gcn_layer.txt
-  python $R/tools/pmc_summary.py $O/pmc_layer_$i gcn_layer >> $O/pmc_gcn_layer.txt
-  python $R/tools/pmc_summary.py $O/pmc_layer_$i hub_reduce >> $O/pmc_gcn_layer.txt
+  python $R/tools/pmc_summary.py $O/pmc_layer_$i set_layer >> $O/pmc_gcn_layer.txt
+  python $R/tools/pmc_summary.py $O/pmc_layer_$i set_hub >> $O/pmc_gcn_layer.txt
 done
 for w in eval_tmall eval_ijcai negsample_tmall metapath_dblp predict_ijcai nc_dblp nc_train_dblp epoch_tmall; do
   timeout -k 10 200 python $R/bench.py --workload $w --steps 10 --warmup 3 > $O/${w}_bench.json 2> $O/${w}_bench.err

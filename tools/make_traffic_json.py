@@ -7,8 +7,9 @@ the 128-B requests of 16-B/lane reads at 64 B), summed per fused layer launch.
 """
 import csv, glob, json, sys, collections
 
-KERNELS = {"tmall": ["gcn_layer_kernel", "hub_reduce_kernel"],
-           "industry": ["lds_rows_kernel", "window_rows_kernel", "hub_reduce_kernel"]}
+# the kernels of one layer launch, per forward layer launch of the timed step (the figure is the mean over the launches)
+KERNELS = {"tmall": [["set_layer_kernel<0>", "set_hub_kernel<0>"], ["set_layer_kernel<1>", "set_hub_kernel<1>"]],
+           "industry": [["lds_rows_kernel", "window_rows_kernel", "hub_reduce_kernel"]]}
 
 
 def means(d, counter):
@@ -28,13 +29,17 @@ args = sys.argv[2:]
 for k in range(0, len(args), 3):
     wl, fd, wd = args[k:k + 3]
     fm, wm = means(fd, "FETCH_SIZE"), means(wd, "WRITE_SIZE")
-    entry, total = {}, 0.0
-    for kern in KERNELS[wl]:
-        fb = sum(v for n, v in fm.items() if kern in n) * 1024 * 2
-        wb = sum(v for n, v in wm.items() if kern in n) * 1024
-        entry[kern] = {"fetch_bytes": fb, "write_bytes": wb}
-        total += fb + wb
-    entry["traffic_bytes_per_layer_launch"] = total
+    entry, totals = {}, []
+    for launch in KERNELS[wl]:
+        total = 0.0
+        for kern in launch:
+            fb = sum(v for n, v in fm.items() if kern in n) * 1024 * 2
+            wb = sum(v for n, v in wm.items() if kern in n) * 1024
+            entry[kern] = {"fetch_bytes": fb, "write_bytes": wb}
+            total += fb + wb
+        totals.append(total)
+    entry["traffic_bytes_per_layer_launch"] = sum(totals) / len(totals)
+    entry["per_launch"] = totals
     out[wl] = entry
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
