@@ -21,6 +21,7 @@ DG_ACC_REBUILD = 16
 DG_BWD_NORM_FEED = 32
 DG_ROWS_PARTIAL_ONLY, DG_ROWS_FULL_ONLY = 64, 128
 DG_OUT_PLANES, DG_IN_PLANES = 0x200, 0x400
+DG_ACC_SHARED = 0x800
 
 
 class DiffGraphHipError(RuntimeError):

@@ -250,6 +250,68 @@ __global__ __launch_bounds__(256) void partial_finalize_kernel(const dg_task_bat
   epilogue(T, row, rc, acc, l);
 }
 
+// Sum of the LDS table rows on one large-side row's list: `w` is this lane's dword of the row's 64-B record (slot 0 =
+// the degree, then 31 neighbours as 16-bit indices into the table, padding = the zero row n_small); longer lists go on
+// in the CSR.  `t` = table + lane's float4.  The additions run in list order.
+// PAIR: the first eight slots are read together whatever the degree (padding slots name the zero row, and a sum that
+// began at +0 never is -0, so adding it changes no bit): one wait for two blocks where few wavefronts share the CU.
+template <bool PAIR = false>
+__device__ __forceinline__ f32x4 lds_row_sum(const dg_task_dev &T, const f32x4 *__restrict__ t, unsigned w, int row, int n_small,
+                                             int split, int l) {
+  const int deg = bcast16<0>((int)w) & 0xffff;
+  // slot 0 of the record is the degree, not a neighbour: read the zero row for it
+  const unsigned ww = l == 0 ? ((w & 0xffff0000u) | (unsigned)n_small) : w;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (PAIR) {
+    const unsigned a0 = (unsigned)bcast16<0>((int)ww), b0 = (unsigned)bcast16<1>((int)ww);
+    const unsigned a1 = (unsigned)bcast16<2>((int)ww), b1 = (unsigned)bcast16<3>((int)ww);
+    const f32x4 v0 = t[(a0 & 0xffffu) * 16], v1 = t[(a0 >> 16) * 16], v2 = t[(b0 & 0xffffu) * 16], v3 = t[(b0 >> 16) * 16];
+    const f32x4 v4 = t[(a1 & 0xffffu) * 16], v5 = t[(a1 >> 16) * 16], v6 = t[(b1 & 0xffffu) * 16], v7 = t[(b1 >> 16) * 16];
+    acc += v0; acc += v1; acc += v2; acc += v3;
+    acc += v4; acc += v5; acc += v6; acc += v7;
+  }
+#define DG_LDS4(J)                                                                                    \
+  {                                                                                                   \
+    const unsigned a = (unsigned)bcast16<2 * (J)>((int)ww), b = (unsigned)bcast16<2 * (J) + 1>((int)ww); \
+    const f32x4 v0 = t[(a & 0xffffu) * 16], v1 = t[(a >> 16) * 16];                                   \
+    const f32x4 v2 = t[(b & 0xffffu) * 16], v3 = t[(b >> 16) * 16];                                   \
+    acc += v0; acc += v1; acc += v2; acc += v3;                                                       \
+  }
+  if (!PAIR) {
+    DG_LDS4(0)
+    if (deg >= 4) DG_LDS4(1)
+  }
+  if (deg >= 8) DG_LDS4(2)
+  if (deg >= 12) DG_LDS4(3)
+  if (deg >= 16) {
+    DG_LDS4(4)
+    if (deg >= 20) DG_LDS4(5)
+    if (deg >= 24) DG_LDS4(6)
+    if (deg >= 28) DG_LDS4(7)
+  }
+#undef DG_LDS4
+  if (deg > 31) {  // rare: the rest of the list from the CSR
+    const int e = T.rowptr[row + 1];
+    for (int p = T.rowptr[row] + 31; p < e; p += 16) {
+      int c = n_small;
+      if (p + l < e) c = T.colidx[p + l] - split;
+      const int cnt = e - p;
+#define DG_LDS4T(K0)                                                                                  \
+      {                                                                                               \
+        const f32x4 v0 = t[bcast16<K0>(c) * 16], v1 = t[bcast16<K0 + 1>(c) * 16];                     \
+        const f32x4 v2 = t[bcast16<K0 + 2>(c) * 16], v3 = t[bcast16<K0 + 3>(c) * 16];                 \
+        acc += v0; acc += v1; acc += v2; acc += v3;                                                   \
+      }
+      DG_LDS4T(0)
+      if (cnt > 4) DG_LDS4T(4)
+      if (cnt > 8) DG_LDS4T(8)
+      if (cnt > 12) DG_LDS4T(12)
+#undef DG_LDS4T
+    }
+  }
+  return acc;
+}
+
 // Rows [0, lds_split) of a bipartite graph whose other block fits in LDS (see dg_csr::lds_split).
 // A 1024-thread workgroup copies that block's table rows (times their source norm unless the
 // table is already scaled) into LDS once, then walks its share of the rows: 64 rows at a time,
@@ -313,50 +375,164 @@ __global__ __launch_bounds__(1024) void lds_rows_kernel(const dg_task_batch batc
     for (int j = 0; j < R; ++j) {
       const int row = base + 64 * j;
       if (row >= split) continue;
-      const unsigned w = w_cur[j];
-      const int deg = bcast16<0>((int)w) & 0xffff;
-      // slot 0 of the record is the degree, not a neighbour: read the zero row for it
-      const unsigned ww = l == 0 ? ((w & 0xffff0000u) | (unsigned)n_small) : w;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#define DG_LDS4(J)                                                                                    \
-      {                                                                                               \
-        const unsigned a = (unsigned)bcast16<2 * (J)>((int)ww), b = (unsigned)bcast16<2 * (J) + 1>((int)ww); \
-        const f32x4 v0 = t[(a & 0xffffu) * 16], v1 = t[(a >> 16) * 16];                               \
-        const f32x4 v2 = t[(b & 0xffffu) * 16], v3 = t[(b >> 16) * 16];                               \
-        acc += v0; acc += v1; acc += v2; acc += v3;                                                   \
-      }
-      DG_LDS4(0)
-      if (deg >= 4) DG_LDS4(1)
-      if (deg >= 8) DG_LDS4(2)
-      if (deg >= 12) DG_LDS4(3)
-      if (deg >= 16) {
-        DG_LDS4(4)
-        if (deg >= 20) DG_LDS4(5)
-        if (deg >= 24) DG_LDS4(6)
-        if (deg >= 28) DG_LDS4(7)
-      }
-#undef DG_LDS4
-      if (deg > 31) {  // rare: the rest of the list from the CSR
-        const int e = T.rowptr[row + 1];
-        for (int p = T.rowptr[row] + 31; p < e; p += 16) {
-          int c = n_small;
-          if (p + l < e) c = T.colidx[p + l] - split;
-          const int cnt = e - p;
-#define DG_LDS4T(K0)                                                                                  \
-          {                                                                                           \
-            const f32x4 v0 = t[bcast16<K0>(c) * 16], v1 = t[bcast16<K0 + 1>(c) * 16];                 \
-            const f32x4 v2 = t[bcast16<K0 + 2>(c) * 16], v3 = t[bcast16<K0 + 3>(c) * 16];             \
-            acc += v0; acc += v1; acc += v2; acc += v3;                                               \
-          }
-          DG_LDS4T(0)
-          if (cnt > 4) DG_LDS4T(4)
-          if (cnt > 8) DG_LDS4T(8)
-          if (cnt > 12) DG_LDS4T(12)
-#undef DG_LDS4T
-        }
-      }
+      const f32x4 acc = lds_row_sum(T, t, w_cur[j], row, n_small, split, l);
       epilogue(T, row, rc_cur[j], acc, l);
     }
+  }
+}
+
+// The last layer's rows [0, lds_split) of ALL graphs of a layer call in one walk (DG_ACC_SHARED): a 512-thread
+// workgroup takes tiles of 32*R consecutive rows and, tile by tile, goes through the graphs one after the other -- the
+// LDS table is refilled with the next graph's small-side rows between two graphs -- while each 16-lane group keeps
+// its R rows of e0 and of the running sum over tasks 1.. in registers.  Per row the launch reads e0 once and writes
+// two tables (task 0's layer sum; the sum over the other tasks' layer sums, added in task order) instead of reading
+// e0 once per graph, writing a layer sum per graph and adding them up in a further pass.  With up to three graphs
+// the tiles alternate between task order and its reverse, so that a tile starts on the table the one before ended
+// on (two refills per tile, not three; a + b = b + a keeps the sum of two what it was).  The next phase's table and
+// row inputs are asked for before the current phase is summed and wait in registers.  Same arithmetic per (row, graph) as lds_rows_kernel under DG_IN_PRESCALED | DG_ACC_REBUILD, in the same
+// order: the same bits.
+template <int R>
+__global__ __launch_bounds__(512) void lds_sum_rows_kernel(const dg_task_batch batch) {
+  extern __shared__ f32x4 tab[];  // [(n - split) + 1][16]; the last row is zeros (padding neighbour)
+  constexpr int kGroups = 32, kTile = kGroups * R, kFill = (DG_LDS_MAX_ROWS + 1) * 16 / 512;
+  const int G = batch.n_tasks;
+  const int split = batch.t[0].lds_split, n_small = batch.t[0].n - split;
+  const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const int n_tiles = (split + kTile - 1) / kTile, fill_n = (n_small + 1) * 16;
+  const f32x4 *t = tab + l;
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;  // (the whole workgroup)
+
+  static_assert(R <= kFill, "the next tile's e0 rows wait in the table's registers (a tile never begins with a refill)");
+  f32x4 fill[kFill], p_next[R], e0[R], het[R];
+  unsigned w_next[R];
+  float di_next[R], ds_next[R];   // the row's norm, and its norm as a source
+  // Loads only: what the phase after the current one needs -- its table (or, when it begins a tile on the table in
+  // place, the tile's e0 rows, in the same registers), each row's record, norms and stored activation.  They stay in
+  // flight while the current phase is summed.
+  // (Every load goes through a buffer descriptor and is issued whatever the row or the table entry -- beyond the
+  // table it returns zeros -- so that the compiler can count the loads in flight: loads skipped lane by lane would
+  // make it wait for ALL of them before the first use of any.)
+  const int n = batch.t[0].n;
+  auto vec_rsrc = [](const void *base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+  };
+  auto load4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  };
+  const __amdgpu_buffer_rsrc_t r_e0 = table_rsrc(batch.t[0].acc_in, n);
+  auto fetch = [&](int g_next, int tile_next, bool table, bool first) {
+    const dg_task_dev &N = batch.t[__builtin_amdgcn_readfirstlane(g_next)];
+    const __amdgpu_buffer_rsrc_t r_x = table_rsrc(N.x, n), r_head = vec_rsrc(N.lhead, split * 64),
+                                 r_row = vec_rsrc(N.dinv_row, n * 4), r_out = vec_rsrc(N.dinv_out, n * 4);
+    if (table) {
+#pragma unroll
+      for (int k = 0; k < kFill; ++k)   // table row n_small (the zero row) and beyond: past the end of x, zeros
+        fill[k] = load4(r_x, (unsigned)split * 256u + (unsigned)(threadIdx.x + 512 * k) * 16u);
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const unsigned row = (unsigned)(tile_next * kTile + kGroups * j + grp);
+      w_next[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r_head, row * 64u + (unsigned)l * 4u, 0, 0);   // past the last row: 0
+      di_next[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_row, row * 4u, 0, 0));
+      ds_next[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_out, row * 4u, 0, 0));
+      p_next[j] = load4(r_x, row * 256u + (unsigned)l * 16u);
+      if (first) fill[j] = load4(r_e0, row * 256u + (unsigned)l * 16u);   // (the phase has no refill: see below)
+    }
+  };
+  const bool snake = G <= 3;
+  // One loop body issues every prefetch (the first pass through it only fetches): a separate first fetch would land
+  // in other registers, and the waits the compiler then needs for that path would hold up every pass.
+  bool rev = false, table = false, first = false, have = false;
+  int gi = 0, seen = 0;  // seen: tasks 1.. of this tile already summed
+  for (;;) {
+    const dg_task_dev &T = batch.t[__builtin_amdgcn_readfirstlane(gi)];
+    if (table) {
+      __syncthreads();  // every group is done with the previous table
+#pragma unroll
+      for (int k = 0; k < kFill; ++k) {
+        const int i = threadIdx.x + 512 * k;
+        if (i < fill_n) tab[i] = fill[k];
+      }
+      __syncthreads();
+    } else if (first) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) e0[j] = fill[j];
+    }
+    unsigned w[R];
+    float di_[R], ds_[R];
+    f32x4 p[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      w[j] = w_next[j];
+      di_[j] = di_next[j];
+      ds_[j] = ds_next[j];
+      p[j] = p_next[j];
+    }
+    if (first) seen = 0;
+    // what comes after this phase
+    int g_next = gi + (rev ? -1 : 1), tile_next = tile;
+    bool first_next = false, more = true, table_next = true, rev_next = rev;
+    if (!have) {                      // the first phase itself
+      g_next = 0;
+      first_next = true;
+    } else if (g_next < 0 || g_next >= G) {  // the tile ends here
+      tile_next = tile + (int)gridDim.x;
+      more = tile_next < n_tiles;
+      first_next = true;
+      if (snake) {
+        rev_next = !rev;
+        g_next = gi;
+        table_next = false;
+      } else {
+        g_next = 0;
+      }
+    }
+    // (a tile's last phase still reads e0: its successor's e0 rows go to the table's registers; a tile that begins
+    // with a refill -- the first one, and every one without the alternating order -- loads them itself)
+    if (more) fetch(g_next, tile_next, table_next, first_next && !table_next);
+    if (have) {
+      if (first && table) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) e0[j] = load4(r_e0, (unsigned)(tile * kTile + kGroups * j + grp) * 256u + (unsigned)l * 16u);
+      }
+      if (gi > 0) ++seen;
+      const float slope = T.slope;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int row = tile * kTile + kGroups * j + grp;
+        if (row >= split) continue;
+        const f32x4 acc = lds_row_sum<true>(T, t, w[j], row, n_small, split, l);
+        // (epilogue() under DG_IN_PRESCALED | DG_ACC_REBUILD with acc_out and no e_out)
+        const float di = di_[j], dsrc = ds_[j];
+        f32x4 y = acc * di;
+        y.x = y.x > 0.f ? y.x : y.x * slope;
+        y.y = y.y > 0.f ? y.y : y.y * slope;
+        y.z = y.z > 0.f ? y.z : y.z * slope;
+        y.w = y.w > 0.f ? y.w : y.w * slope;
+        const float ss = sum16(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
+        const f32x4 yn = y * inv_norm(ss);
+        f32x4 a = e0[j];
+        const f32x4 pv = p[j];
+        const float ps = sum16(pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w);
+        a += pv * fminf(__builtin_amdgcn_rsqf(ps), 1e12f * __builtin_amdgcn_rcpf(dsrc));
+        const f32x4 res = a + yn;
+        const size_t o = (size_t)row * 16 + l;
+        if (gi == 0) {
+          store_stream(T.acc_out, o, res);
+        } else {
+          het[j] = seen == 1 ? res : (rev ? res + het[j] : het[j] + res);
+          if (seen == G - 1) store_stream(T.acc_out, o, het[j]);
+        }
+      }
+    }
+    if (!more) break;
+    have = true;
+    first = first_next;
+    gi = g_next;
+    tile = tile_next;
+    rev = rev_next;
+    table = table_next;
   }
 }
 
@@ -821,6 +997,34 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     if (dense_chunks_max > 0) hipLaunchKernelGGL(dense_split_kernel, dim3(dense_chunks_max, n_tasks), dim3(256), 0, stream, batch);
     hipLaunchKernelGGL(dense_rows_kernel, dim3(batch.gather_blocks + dense_blocks), dim3(64 * kDenseWaves), 0, stream, batch);
     if (batch.gather_blocks > 0) blocks = 0;
+  }
+  if (batch.t[0].flags & DG_ACC_SHARED) {
+    // the rows below lds_split of all tasks in one walk, two output tables (lds_sum_rows_kernel)
+    if (rows_sel != DG_ROWS_FULL_ONLY)
+      return dg_fail(DG_ERR_ARG, "layer task: DG_ACC_SHARED comes with DG_ROWS_FULL_ONLY (the other rows are summed per task)");
+    constexpr int32_t need = DG_IN_PRESCALED | DG_ACC_REBUILD | DG_ACC_SHARED;
+    for (int k = 0; k < n_tasks; ++k) {
+      const dg_task_dev &t = batch.t[k];
+      if ((t.flags & need) != need || t.e_out || !t.acc_out || t.row_norm || t.n != batch.t[0].n ||
+          t.lds_split != batch.t[0].lds_split || t.acc_in != batch.t[0].acc_in)
+        return dg_fail(DG_ERR_ARG, "layer task %d: DG_ACC_SHARED needs DG_IN_PRESCALED | DG_ACC_REBUILD on every task, no e_out, no "
+                       "row_norm_out, one acc_in, and graphs of one size with the same side held in LDS", k);
+      if (k >= 1 && (t.acc_out != batch.t[1].acc_out || t.acc_out == batch.t[0].acc_out))
+        return dg_fail(DG_ERR_ARG, "layer task %d: under DG_ACC_SHARED tasks 1.. name one acc_out table, task 0 another", k);
+    }
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    constexpr int rows_per_group = 6;   // (8 rows per group spill registers)
+    const int32_t split = batch.t[0].lds_split, tile = 32 * rows_per_group;
+    const int32_t grid = std::min(std::max(1, cus - kExchangeCus), (split + tile - 1) / tile);
+    const size_t lds_bytes = (size_t)(batch.t[0].n - split + 1) * DG_D * sizeof(float);
+    for (int k = n_tasks; k < DG_MAX_TASKS; ++k) batch.t[k] = batch.t[0];
+    static std::atomic<uint64_t> opted{0};
+    DG_HIP(dg_lds_opt_in(reinterpret_cast<const void *>(lds_sum_rows_kernel<rows_per_group>),
+                         (DG_LDS_MAX_ROWS + 1) * DG_D * (int)sizeof(float), opted));
+    hipLaunchKernelGGL(lds_sum_rows_kernel<rows_per_group>, dim3(grid), dim3(512), lds_bytes, stream, batch);
+    DG_HIP(hipGetLastError());
+    return 0;
   }
   if (lds_blocks > 0 && full_rows) {
     const size_t lds_bytes = (size_t)(lds_rows_max + 1) * DG_D * sizeof(float);

@@ -27,7 +27,8 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ._lib import DG_ACC_REBUILD, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE, DG_ROWS_FULL_ONLY, DG_ROWS_PARTIAL_ONLY
+from ._lib import (DG_ACC_REBUILD, DG_ACC_SHARED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE, DG_ROWS_FULL_ONLY,
+                   DG_ROWS_PARTIAL_ONLY)
 
 
 def user_ranges(n_user: int, world: int) -> List[Tuple[int, int]]:
@@ -64,6 +65,7 @@ def shard_bipartite(u: np.ndarray, i: np.ndarray, n_user: int, n_item: int, u0: 
 
 class HipBackend:
     """The product backend: CSRGraph handles and fused HIP launches."""
+    sums_in_layer = True      # layer() takes DG_ACC_SHARED
 
     def __init__(self, device):
         self.device = device
@@ -238,7 +240,9 @@ class ShardedRecPropagation:
         self.edges_global = [lg.n_edges_global for lg in self.local]
         self.hook = None
         # two launches per layer (item partial sums, then the user rows beside the exchange) where the kernels allow
-        self.split_rows = world > 1 and backend.can_split_rows(self.graphs, self.n_loc)
+        self.split_rows = backend.can_split_rows(self.graphs, self.n_loc)
+        # ... and then the last layer's user rows of all graphs in one walk that writes `ui` and `het` directly
+        self.sum_in_layer = n_layers == 2 and len(self.graphs) >= 2 and getattr(backend, "sums_in_layer", False)
         self.reuse_buffers = reuse_buffers
         self._programs = {}
 
@@ -251,6 +255,7 @@ class ShardedRecPropagation:
         """Allocates the buffers of a forward pass over `e0` and prepares its launches.
         Returns (steps, (ui, het)): calling the steps in order fills the two output tables."""
         be, G, L = self.backend, len(self.graphs), self.n_layers
+        sum_in_layer = self.split_rows and self.sum_in_layer
         sums = [be.empty(self.n) for _ in range(G)]
         prev: List[Optional[torch.Tensor]] = [None] * G
         steps, tail = [], []       # tail: the previous layer's wait + finalize, still to be placed
@@ -288,7 +293,14 @@ class ShardedRecPropagation:
                 # rows of its own layer and the partial sums of the next.
                 steps += [be.prepare_layer([dict(t, flags=t["flags"] | DG_ROWS_PARTIAL_ONLY) for t in tasks]), start]
                 steps += tail
-                steps.append(be.prepare_layer([dict(t, flags=t["flags"] | DG_ROWS_FULL_ONLY) for t in tasks]))
+                if last and sum_in_layer:
+                    # the user rows of `het` come straight out of the layer: no layer sum per behaviour graph is
+                    # written for them (the item rows' sums, 361 rows per graph on the Industry shape, are added below)
+                    het = sums[1] if G == 2 else be.empty(self.n)
+                    steps.append(be.prepare_layer([dict(t, flags=t["flags"] | DG_ROWS_FULL_ONLY | DG_ACC_SHARED,
+                                                        acc_out=sums[0] if g == 0 else het) for g, t in enumerate(tasks)]))
+                else:
+                    steps.append(be.prepare_layer([dict(t, flags=t["flags"] | DG_ROWS_FULL_ONLY) for t in tasks]))
             else:
                 steps += tail + [be.prepare_layer(tasks), start]
             tail = [wait, fin]
@@ -296,7 +308,9 @@ class ShardedRecPropagation:
         steps += tail
         steps.insert(0, lambda: self.hook and self.hook("begin"))     # (timing hook round the layers, not the final sum)
         steps.append(lambda: self.hook and self.hook("end"))
-        if G > 2:
+        if G > 2 and sum_in_layer:
+            steps.append(be.prepare_sum([t[self.n_loc:] for t in sums[1:]], het[self.n_loc:]))   # the item rows
+        elif G > 2:
             het = be.empty(self.n)
             steps.append(be.prepare_sum(sums[1:], het))
         else:

@@ -132,6 +132,12 @@ enum { DG_ROWS_PARTIAL_ONLY = 64, DG_ROWS_FULL_ONLY = 128 };
  * one call with neither flag.  All tasks of a call carry the same choice.  Accepted for graphs
  * whose schedule keeps the two row classes in separate launches (one small side held in LDS, with
  * partial_from equal to the first row of that side); an argument error otherwise. */
+enum { DG_ACC_SHARED = 0x800 };
+/* With DG_ROWS_FULL_ONLY on the last layer (DG_IN_PRESCALED | DG_ACC_REBUILD, no e_out): the tasks' rows are walked
+ * together, row by row through all graphs, and only two tables are written -- task 0's acc_out as usual, and ONE table
+ * named as acc_out by every task from 1 on, which receives the sum of those tasks' layer sums, added in task order
+ * (HGDM.forward only ever adds them up, DiffGraph-Rec/Model.py:73-87).  Each value equals, bit for bit, what separate
+ * tasks followed by dg_sum_tables give.  All tasks: the same acc_in, graphs of one size with the same side in LDS. */
 
 typedef struct dg_layer_task {
   dg_graph *graph;

@@ -978,7 +978,7 @@ def test_sharded_lds_graphs_split_layer_calls():
     inter = [dgdata.synth_interactions(nu, ni, m, seed) for m, seed in ((30000, 1), (80000, 2), (12000, 3))]
     ue, ie = T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))
     probe = ShardedRecPropagation(inter, nu, ni, 1, world, HipBackend(torch.device(DEV)))
-    assert probe.split_rows
+    assert probe.split_rows and probe.sum_in_layer     # (the last layer's user rows: one walk over the graphs, `het` written directly)
     res = _run_sharded_threads(inter, nu, ni, ue, ie, world)
     tu, ti, hu, hi = O.rec_forward(edges_t(*inter[0], nu), [edges_t(*b, nu) for b in inter[1:]], ue, ie, 2)
     assert_rows_close(torch.cat([r[2][: r[1] - r[0]] for r in res]), tu, what="split calls: target users")
@@ -992,8 +992,45 @@ def test_sharded_lds_graphs_split_layer_calls():
     probe._exchange = lambda p, out: _Pending(torch.stack([p, p, p], out=out))
     a = [t.clone() for t in probe.forward(e0)]
     probe.split_rows = False
-    b = probe.forward(e0)
+    b = [t.clone() for t in probe.forward(e0)]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # ... and two calls with a layer sum per graph, added up afterwards
+    probe.split_rows, probe.sum_in_layer = True, False
+    c = probe.forward(e0)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+
+
+def test_shared_layer_sum_flag_is_checked():
+    """DG_ACC_SHARED: only with DG_ROWS_FULL_ONLY on the last layer of graphs with one side in LDS, tasks 1.. naming one table."""
+    from diffgraph_amd._lib import (DG_ACC_REBUILD, DG_ACC_SHARED, DG_IN_PRESCALED, DG_ROWS_FULL_ONLY, DiffGraphHipError)
+    nu, ni = 3000, 20
+    gs = [dg.CSRGraph.from_bipartite(*dgdata.synth_interactions(nu, ni, 9000, seed), nu, ni) for seed in (1, 2, 3, 4)]
+    assert all(g.schedule()["lds_split"] == nu for g in gs)
+    n = nu + ni
+    e0, x = dev(torch.randn(n, 64)), [dev(torch.randn(n, 64)) for _ in gs]
+    ui, het, other = (torch.empty(n, 64, device=DEV) for _ in range(3))
+    part = [torch.empty(ni, 64, device=DEV) for _ in gs]
+    flags = DG_IN_PRESCALED | DG_ACC_REBUILD | DG_ROWS_FULL_ONLY | DG_ACC_SHARED
+
+    def task(g, out, fl=flags):
+        return ops.LayerTask(graph=gs[g], x=x[g], e_out=None, acc_in=e0, acc_out=out, flags=fl, slope=0.5,
+                             partial_out=part[g], partial_from=nu)
+    sep = [torch.empty(n, 64, device=DEV) for _ in gs]
+    ops.gcn_layer_batched([task(g, sep[g], flags & ~DG_ACC_SHARED) for g in range(4)])   # a layer sum per graph
+    for G in (2, 3, 4):      # (up to three graphs the tiles alternate between task order and its reverse)
+        ui.fill_(float("nan")); het.fill_(float("nan"))
+        ops.gcn_layer_batched([task(g, ui if g == 0 else het) for g in range(G)])
+        want = sep[1].clone()
+        for g in range(2, G):
+            want += sep[g]
+        assert torch.equal(ui[:nu], sep[0][:nu]) and torch.equal(het[:nu], want[:nu]), G
+        assert torch.isnan(ui[nu:]).all() and torch.isnan(het[nu:]).all()      # the other rows are not this call's
+    with pytest.raises(DiffGraphHipError):
+        ops.gcn_layer_batched([task(0, ui), task(1, het), task(2, other)])               # two tables for tasks 1..
+    with pytest.raises(DiffGraphHipError):
+        ops.gcn_layer_batched([task(0, het), task(1, het), task(2, het)])                # task 0 shares it
+    with pytest.raises(DiffGraphHipError):
+        ops.gcn_layer_batched([task(g, [ui, het, het][g], flags & ~DG_ROWS_FULL_ONLY) for g in range(3)])
 
 
 def test_graph_device_argument():
