@@ -8,6 +8,12 @@ Differences a caller can see:
   * The noise-schedule tables are built in fp64 on the host with the reference's torch ops,
     then cast to fp32 device tables once (the reference indexes the fp64 table and casts
     the gathered values, which gives the same fp32 numbers).
+  * Two ways through a Denoise.  The reference's default shape -- dims='[64]', d_emb_size=8: one 72->64 and one
+    64->64 layer -- runs in the fused kernels (csrc/diffusion.hip: denoiser, loss and reverse loop as single
+    launches).  Any other `--dims` list or `--d_emb_size` (params.py:32-33) runs layer by layer: every nn.Linear
+    through the HIP dense-layer kernels (dg_linear_fwd / dg_linear_wgrad, csrc/linear.hip), the elementwise steps
+    between them (normalise, dropout, tanh, the loss) as torch device ops under autograd.  Correct for every
+    configuration the reference accepts at latdim 64; only the default shape is tuned.
 """
 from __future__ import annotations
 
@@ -22,19 +28,42 @@ from . import ops
 from ._lib import DG_D, DiffGraphHipError
 
 
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear (y = x . w^T + b) through the HIP dense-layer kernels, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = x.contiguous(), w.contiguous()
+        ctx.save_for_backward(x, w)
+        return ops.linear_fwd(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        d_x = ops.linear_fwd(dy, w.t().contiguous(), None) if ctx.needs_input_grad[0] else None
+        d_w, d_b = ops.linear_wgrad(dy, x)
+        return d_x, d_w, d_b
+
+
 class Denoise(nn.Module):
-    """Denoise(in_dims, out_dims, emb_size, norm, dropout) -- Model.py:176-234."""
+    """Denoise(in_dims, out_dims, emb_size, norm, dropout) -- Model.py:176-234.  `fused`: the layer shapes the fused
+    kernels are built for (in_dims = out_dims = [64, 64], emb_size 8); other shapes run layer by layer."""
 
     def __init__(self, in_dims, out_dims, emb_size, norm=False, dropout=0.5):
         super().__init__()
-        if list(in_dims) != [DG_D, DG_D] or list(out_dims) != [DG_D, DG_D] or emb_size != 8:
-            raise NotImplementedError("kernels are built for dims='[64]', latdim=64, d_emb_size=8 (the reference defaults)")
+        in_dims, out_dims = list(in_dims), list(out_dims)
+        if len(in_dims) < 2 or len(out_dims) < 2 or in_dims[0] != DG_D or out_dims[-1] != DG_D or emb_size < 1:
+            raise NotImplementedError(f"the embedding tables are {DG_D} wide (latdim={DG_D}): a denoiser takes and returns "
+                                      f"rows of that width, got in_dims {in_dims}, out_dims {out_dims}")
         self.in_dims, self.out_dims = in_dims, out_dims
         self.time_emb_dim = emb_size
         self.norm = norm
+        self.fused = in_dims == [DG_D, DG_D] and out_dims == [DG_D, DG_D] and emb_size == 8
         self.emb_layer = nn.Linear(emb_size, emb_size)
-        self.in_layers = nn.ModuleList([nn.Linear(DG_D + emb_size, DG_D)])
-        self.out_layers = nn.ModuleList([nn.Linear(DG_D, DG_D)])
+        in_temp = [in_dims[0] + emb_size] + in_dims[1:]                                       # Model.py:186-191
+        self.in_layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(in_temp[:-1], in_temp[1:])])
+        self.out_layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(out_dims[:-1], out_dims[1:])])
         self.drop = nn.Dropout(dropout)
         self.init_weights()
         self._params = {}
@@ -48,6 +77,8 @@ class Denoise(nn.Module):
 
     def params(self, norm: bool) -> ops.DenoiserParams:
         """Kernel-side view of the weights (pointers stay valid across in-place optimiser steps)."""
+        if not self.fused:
+            raise DiffGraphHipError("Denoise.params(): the fused kernels take the default layer shapes only")
         ws = (self.emb_layer.weight, self.emb_layer.bias, self.in_layers[0].weight, self.in_layers[0].bias,
               self.out_layers[0].weight, self.out_layers[0].bias)
         key = (bool(norm),) + tuple(w.data_ptr() for w in ws)
@@ -60,6 +91,8 @@ class Denoise(nn.Module):
 
     def forward(self, x, timesteps, mess_dropout=True, keep_mask=None):
         """keep_mask (uint8 / bool [n, 64]): the dropout mask to apply in train() mode instead of a fresh draw."""
+        if not self.fused:
+            return self.forward_layers(x, timesteps, mess_dropout, keep_mask)
         n_steps = int(getattr(self, "n_steps", 0)) or int(timesteps.max().item()) + 1
         p = self.params(bool(self.norm))
         p.time_bias(n_steps, refresh=True)
@@ -70,6 +103,32 @@ class Denoise(nn.Module):
             return ops.denoise_fwd(p, x.contiguous(), timesteps, n_steps, drop_p=float(self.drop.p), keep_mask=keep_mask,
                                    drop_seed=seed)
         return ops.denoise_fwd(p, x.contiguous(), timesteps, n_steps)
+
+    def forward_layers(self, x, timesteps, mess_dropout=True, keep_mask=None):
+        """Model.py:214-234 layer by layer, differentiable: the Linear layers in the HIP dense-layer kernels."""
+        E = self.time_emb_dim
+        half = E // 2
+        freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32, device=x.device) / half)
+        temp = timesteps[:, None].float() * freqs[None]
+        time_emb = torch.cat([torch.cos(temp), torch.sin(temp)], dim=-1)
+        if E % 2:
+            time_emb = torch.cat([time_emb, torch.zeros_like(time_emb[:, :1])], dim=-1)
+        emb = _LinearFn.apply(time_emb, self.emb_layer.weight, self.emb_layer.bias)
+        if self.norm:
+            x = torch.nn.functional.normalize(x)
+        if mess_dropout and self.training and self.drop.p > 0:
+            if keep_mask is not None:
+                x = x * (keep_mask.to(x.dtype) * (1.0 / (1.0 - float(self.drop.p))))
+            else:
+                x = self.drop(x)
+        h = torch.cat([x, emb], dim=-1)
+        for layer in self.in_layers:
+            h = torch.tanh(_LinearFn.apply(h, layer.weight, layer.bias))
+        for i, layer in enumerate(self.out_layers):
+            h = _LinearFn.apply(h, layer.weight, layer.bias)
+            if i != len(self.out_layers) - 1:
+                h = torch.tanh(h)
+        return h
 
 
 def dropout_rate(models) -> float:
@@ -212,14 +271,29 @@ class GaussianDiffusion(nn.Module):
             t = torch.full((x_start.shape[0],), steps - 1, dtype=torch.long, device=x_start.device)
             x_t = self.q_sample(x_start, t, noise)
         dev = x_start.device
+        if not model.fused:
+            return self._p_sample_layers(model, x_t)
         p = model.params(bool(model.norm))
         p.time_bias(self.steps, refresh=True)
         return ops.p_sample_loop(p, x_t.contiguous(), self._dev("posterior_mean_coef1", dev),
                                  self._dev("posterior_mean_coef2", dev))
 
+    def _p_sample_layers(self, model, x_t):
+        """The reverse loop of Model.py:293-300 step by step (a denoiser outside the fused kernels' shape)."""
+        dev = x_t.device
+        c1, c2 = self._dev("posterior_mean_coef1", dev), self._dev("posterior_mean_coef2", dev)
+        with torch.no_grad():
+            for i in range(self.steps - 1, -1, -1):
+                t = torch.full((x_t.shape[0],), i, dtype=torch.long, device=dev)
+                x_t = c1[i] * model.forward_layers(x_t, t, False) + c2[i] * x_t        # model_mean (Model.py:323)
+        return x_t
+
     def p_sample_many(self, pairs, steps, noises=None):
         """p_sample for several (model, x_start) pairs in one fused launch (HGDM.predict runs the user and
         the item denoiser back to back, Model.py:114-115)."""
+        if any(not model.fused for model, _ in pairs):
+            return [self.p_sample(model, x_start, steps, None if noises is None else noises[k])
+                    for k, (model, x_start) in enumerate(pairs)]
         prepared = []
         for k, (model, x_start) in enumerate(pairs):
             if steps == 0:
@@ -252,6 +326,8 @@ class GaussianDiffusion(nn.Module):
             ts = torch.randint(0, self.steps, (n,), device=dev).long()
         if noise is None and self.noise_scale != 0:
             noise = torch.randn_like(x_start)
+        if not model.fused:
+            return self._training_losses_layers(model, targetEmbeds, x_start, ts, noise, keep_mask)
         norm = bool(model.norm)
         xs = x_start.contiguous()
         drop = dropout_args([model], keep_mask, dev, drop_seed)
@@ -267,6 +343,18 @@ class GaussianDiffusion(nn.Module):
         return ops.diffusion_loss_fwd_spans([ops.LossSpan(p, 0, n, drop[0])], targetEmbeds.contiguous(), xs, noise, ts, sa, sb,
                                             self._dev("loss_weight", dev, torch.float64), validate=validate,
                                             keep_mask=drop[1], drop_seed=drop[2])
+
+    def _training_losses_layers(self, model, targetEmbeds, x_start, ts, noise, keep_mask):
+        """Model.py:348-365 for a denoiser outside the fused kernels' shape: q_sample, the model layer by layer, the
+        SNR-weighted mean square -- differentiable torch ops round the HIP dense layers."""
+        dev = x_start.device
+        x_t = x_start
+        if self.noise_scale != 0:
+            sa, sb = self._dev("sqrt_alphas_cumprod", dev), self._dev("sqrt_one_minus_alphas_cumprod", dev)
+            x_t = sa[ts][:, None] * x_start + sb[ts][:, None] * noise                 # q_sample (Model.py:302-305)
+        out = model.forward_layers(x_t, ts, True, keep_mask)
+        mse = self.mean_flat((targetEmbeds - out) ** 2)
+        return self._dev("loss_weight", dev, torch.float64)[ts] * mse, out            # (SNR(t-1) - SNR(t), 1 at t = 0)
 
     def mean_flat(self, tensor):  # Model.py:368-369
         return tensor.mean(dim=list(range(1, len(tensor.shape))))

@@ -430,6 +430,8 @@ class HGDM(nn.Module):
         dp = self.diffusion_process
         dev, n = self.embedding_table.device, self.n_user + self.n_item
         denoisers = [self.usr_denoiser, self.item_denoiser]
+        if not all(dn.fused for dn in denoisers):
+            return self._cal_loss_layers(ancs, poss, negs, ts_u, noise_u, ts_i, noise_i, keep_u, keep_i)
         if validate is None:   # caller-supplied timesteps are range-checked (one host sync) unless the caller vouches for them
             validate = ts_u is not None or ts_i is not None
         keep = None
@@ -465,6 +467,16 @@ class HGDM(nn.Module):
             weights += [dn.emb_layer.weight, dn.emb_layer.bias, dn.in_layers[0].weight, dn.in_layers[0].bias,
                         dn.out_layers[0].weight, dn.out_layers[0].bias]
         return _RecLossFn.apply(ui, het, noise, ts, ancs, poss, negs, self, validate, drop, *weights)
+
+    def _cal_loss_layers(self, ancs, poss, negs, ts_u, noise_u, ts_i, noise_i, keep_u, keep_i) -> torch.Tensor:
+        """cal_loss (Model.py:94-111) for denoisers outside the fused kernels' shape (another --dims list or
+        --d_emb_size): the propagation and the loss head as always, the two training_losses2 calls layer by layer."""
+        dp, nu = self.diffusion_process, self.n_user
+        ui, het = self.propagate(self.embedding_table)
+        rl_u, out_u = dp.training_losses_rows(self.usr_denoiser, ui[:nu], het[:nu], ts_u, noise_u, keep_u)
+        rl_i, out_i = dp.training_losses_rows(self.item_denoiser, ui[nu:], het[nu:], ts_i, noise_i, keep_i)
+        ancs, poss, negs = (v.long().contiguous() for v in (ancs, poss, negs))
+        return _RecHeadFn.apply(ui, out_u, out_i, rl_u, rl_i, ancs, poss, negs, nu, float(self.args.batch), float(self.args.reg))
 
     def predict(self):  # Model.py:112-118
         usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = self.forward()

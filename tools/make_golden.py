@@ -308,6 +308,78 @@ def gen_rec_train():
     print("rec_tiny_train.npz:", len(fx), "arrays; keep fractions", fx["keep_u"].mean(), fx["keep_i"].mean())
 
 
+def denoiser_layers(dn, prefix):
+    """Every tensor of a Denoise with any number of layers: emb, in0.., out0.."""
+    out = {prefix + "emb_w": np64(dn.emb_layer.weight), prefix + "emb_b": np64(dn.emb_layer.bias)}
+    for kind, layers in (("in", dn.in_layers), ("out", dn.out_layers)):
+        for k, layer in enumerate(layers):
+            out[f"{prefix}{kind}{k}_w"], out[f"{prefix}{kind}{k}_b"] = np64(layer.weight), np64(layer.bias)
+    return out
+
+
+def gen_rec_dims():
+    """The tiny Rec model with a second denoiser configuration, --dims '[128, 32]' --d_emb_size 10 (in_layers
+    74->32->128, out_layers 128->32->64; params.py:32-33, Model.py:177-191,226-232): Denoise.forward, training_losses2,
+    p_sample, predict, and cal_loss + backward in eval and in training mode, with the draws torch made recorded."""
+    Model = import_reference("DiffGraph-Rec")
+    from diffgraph_amd import data as dgdata
+    Model.args.dims, Model.args.d_emb_size = "[128, 32]", 10
+    wl = dgdata.rec_workload("tiny")
+    model, handler = build_rec_model(Model, wl, seed=7)
+    nu, ni = wl.n_user, wl.n_item
+    assert [tuple(l.weight.shape) for l in model.usr_denoiser.in_layers] == [(32, 74), (128, 32)]
+    assert [tuple(l.weight.shape) for l in model.usr_denoiser.out_layers] == [(32, 128), (64, 32)]
+    fx = {"dims": np.array([128, 32]), "d_emb_size": np.array([10])}
+    fx.update(denoiser_layers(model.usr_denoiser, "usr_"))
+    fx.update(denoiser_layers(model.item_denoiser, "item_"))
+    dp = model.diffusion_process
+    with torch.no_grad():
+        tu, ti, hu, hi = model.forward()
+        g = torch.Generator().manual_seed(11)
+        t_q = torch.randint(0, 200, (nu,), generator=g)
+        t_q[:4] = torch.tensor([0, 1, 199, 100])
+        fx["q_t"] = np64(t_q)
+        fx["dn_out_mixed"] = np64(model.usr_denoiser(hu, t_q, False))
+        fx["ps_usr_x0"] = np64(dp.p_sample(model.usr_denoiser, hu, 0))
+        batch = torch.tensor([0, 3, 3, 17, nu - 1, 5, 9, 9], dtype=torch.long)
+        with Recorder() as rec:
+            torch.manual_seed(13)
+            loss, out = dp.training_losses2(model.usr_denoiser, tu, hu, batch)
+        fx["tl_ts"], fx["tl_noise"], fx["tl_batch"] = np64(rec.randint[0]), np64(rec.randn[0]), np64(batch)
+        fx["tl_loss"], fx["tl_out"] = np64(loss), np64(out)
+        fx["predict_u"], fx["predict_i"] = map(np64, model.predict())
+    g = torch.Generator().manual_seed(17)
+    B = 64
+    ancs, poss, negs = torch.randint(0, nu, (B,), generator=g), torch.randint(0, ni, (B,), generator=g), torch.randint(0, ni, (B,), generator=g)
+    fx["cl_ancs"], fx["cl_poss"], fx["cl_negs"] = np64(ancs), np64(poss), np64(negs)
+    ue, ie = model.embedding_dict["user_emb"], model.embedding_dict["item_emb"]
+    for mode, seed in (("eval", 19), ("train", 37)):
+        model.train(mode == "train")
+        model.zero_grad()
+        with Recorder() as rec:
+            torch.manual_seed(seed)
+            loss, bpr, reg, diff = model.cal_loss(ancs, poss, negs)
+        loss.backward()
+        pre = mode + "_"
+        fx[pre + "ts_u"], fx[pre + "ts_i"] = np64(rec.randint[0]), np64(rec.randint[1])
+        fx[pre + "noise_u"], fx[pre + "noise_i"] = np64(rec.randn[0]), np64(rec.randn[1])
+        if mode == "train":
+            assert len(rec.dropout) == 2
+            fx[pre + "keep_u"], fx[pre + "keep_i"] = (np64(m).astype(np.uint8) for m in rec.dropout)
+        fx[pre + "losses"] = np.array([loss.item(), bpr.item(), reg.item(), diff.item()], dtype=np.float64)
+        fx[pre + "grad_user"], fx[pre + "grad_item"] = np64(ue.grad), np64(ie.grad)
+        for who, dn in (("usr_", model.usr_denoiser), ("item_", model.item_denoiser)):
+            grads = {"emb_w": dn.emb_layer.weight.grad, "emb_b": dn.emb_layer.bias.grad}
+            for kind, layers in (("in", dn.in_layers), ("out", dn.out_layers)):
+                for k, layer in enumerate(layers):
+                    grads[f"{kind}{k}_w"], grads[f"{kind}{k}_b"] = layer.weight.grad, layer.bias.grad
+            for nm, q in grads.items():
+                fx[pre + "grad_" + who + nm] = np64(q)
+    fx["cl_batch_div"] = np.array([Model.args.batch, Model.args.reg], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "rec_tiny_dims.npz"), **fx)
+    print("rec_tiny_dims.npz:", len(fx), "arrays")
+
+
 # --------------------------------------------------------------------------------------
 # NC (DBLP)
 # --------------------------------------------------------------------------------------
@@ -551,9 +623,9 @@ def gen_metapath():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "rec_train", "nc", "nc_train", "eval", "metapath"]
+    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "nc", "nc_train", "eval", "metapath"]
     if len(which) == 1:
-        {"rec": gen_rec, "rec_train": gen_rec_train, "nc": gen_nc, "nc_train": gen_nc_train, "eval": gen_eval,
+        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "nc": gen_nc, "nc_train": gen_nc_train, "eval": gen_eval,
          "metapath": gen_metapath}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
