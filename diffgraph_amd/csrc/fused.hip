@@ -54,7 +54,7 @@ constexpr int kHeadSlots = 12;
 constexpr int kGroupPiece = 32;
 constexpr int kRuns = 8;
 
-enum { M_FIRST = 0, M_LAST = 1, M_BWD_MID = 2, M_BWD_TOP = 3, M_BWD_LAST = 4 };
+enum { M_FIRST = 0, M_LAST = 1, M_BWD_MID = 2, M_BWD_TOP = 3, M_BWD_LAST = 4, M_BWD_LAST_ADAM = 5 };
 
 struct set_dev {
   const int32_t *col, *head, *hub_desc, *seg_desc, *gseg_desc;
@@ -70,12 +70,18 @@ struct set_dev {
   const float *d_first, *d_rest;  // backward: gradients wrt the two sums
   int32_t n, n_graphs, n_hub, n_seg_slots, n_gseg_slots, n_rec;
   float slope;
+  // M_BWD_LAST_ADAM: the table the gradient belongs to, its Adam moments and state {steps taken, ..}
+  float *adam_p, *adam_m, *adam_v;
+  float *adam_state;
+  float lr, beta1, beta2, eps, weight_decay;
 };
 
 struct set_ctx {
+  float adam_t;    // M_BWD_LAST_ADAM: the step count of this update
   float sc;        // lanes 0..7 of the group: the row's norms
   f32x4 a, b;      // M_LAST: a = e0[row]; backward: gradients wrt the first / the other graphs' sums
   f32x4 own[kMaxSetGraphs];  // M_LAST: the row's own first-layer activations; backward: its saved activations
+                             // (M_BWD_LAST_ADAM: the row of the parameter table and of its two moments)
 };
 
 // Loads only: the requests stay in flight while the neighbour rows are gathered.
@@ -89,6 +95,14 @@ __device__ __forceinline__ void load_set_ctx(const set_dev &T, int row, int l, s
 #pragma unroll
   for (int g = 0; g < kMaxSetGraphs; ++g) c.own[g] = z;
   if (MODE == M_FIRST || MODE == M_BWD_LAST) return;
+  if (MODE == M_BWD_LAST_ADAM) {
+    c.a = load_stream(T.d_first, o);
+    c.b = load_stream(T.d_rest, o);
+    c.own[0] = load_stream(T.adam_p, o);
+    c.own[1] = load_stream(T.adam_m, o);
+    c.own[2] = load_stream(T.adam_v, o);
+    return;
+  }
   const float *own = MODE == M_LAST ? T.x : T.e_saved;
   if (MODE == M_LAST) {
     c.a = load_stream(T.e0, o);
@@ -160,13 +174,39 @@ __device__ __forceinline__ void set_epilogue_one(const set_dev &T, size_t o, con
 template <int MODE>
 __device__ __forceinline__ void set_epilogue(const set_dev &T, int row, int l, const set_ctx &c, const f32x4 (&sums)[4]) {
   const size_t o = (size_t)row * (DG_D / 4) + l;
-  if (MODE == M_BWD_LAST) {
+  if (MODE == M_BWD_LAST || MODE == M_BWD_LAST_ADAM) {
     // the last backward step is linear: d e0 gets sum_g dinv_g[row] * (sum over N_g(row) of dZ_1 of graph g), one table
     f32x4 g0 = sums[0] * bcast16f<4>(c.sc);
     g0 += sums[1] * bcast16f<5>(c.sc);
     if (T.n_graphs > 2) g0 += sums[2] * bcast16f<6>(c.sc);
     if (T.n_graphs > 3) g0 += sums[3] * bcast16f<7>(c.sc);
-    store_stream(T.sum_first, o, g0);
+    if (MODE == M_BWD_LAST) {
+      store_stream(T.sum_first, o, g0);
+      return;
+    }
+    // ... and the table's Adam step on the spot.  Every graph's layer sum starts from e0 (Model.py:57,74), so the
+    // gradient is d_first + d_rest (once per behaviour graph) + g0, added left to right; then torch.optim.Adam's
+    // update with the step count t = steps taken + 1 -- the arithmetic, term for term, of adam_prepare_kernel and
+    // adam_table_kernel (optim.hip), which form the same sum from the same tables: the same bits.
+    f32x4 g = c.a + c.b;
+    if (T.n_graphs > 2) g += c.b;
+    if (T.n_graphs > 3) g += c.b;
+    g += g0;
+    const float t = c.adam_t;
+    const float bc1 = 1.0f - powf(T.beta1, t), bc2_sqrt = sqrtf(1.0f - powf(T.beta2, t));
+    const float step_size = T.lr / bc1;
+    f32x4 p = c.own[0], m = c.own[1], v = c.own[2];
+    if (T.weight_decay != 0.f) g += p * T.weight_decay;
+    m = m + (g - m) * (1.0f - T.beta1);
+    v = v * T.beta2 + g * g * (1.0f - T.beta2);
+    f32x4 dn;
+    dn.x = sqrtf(v.x) / bc2_sqrt + T.eps; dn.y = sqrtf(v.y) / bc2_sqrt + T.eps;
+    dn.z = sqrtf(v.z) / bc2_sqrt + T.eps; dn.w = sqrtf(v.w) / bc2_sqrt + T.eps;
+    p.x -= step_size * (m.x / dn.x); p.y -= step_size * (m.y / dn.y);
+    p.z -= step_size * (m.z / dn.z); p.w -= step_size * (m.w / dn.w);
+    store_stream(T.adam_p, o, p);
+    store_stream(T.adam_m, o, m);
+    store_stream(T.adam_v, o, v);
     return;
   }
   f32x4 S0, S1, S2, S3;
@@ -246,6 +286,10 @@ __global__ __launch_bounds__(256) void set_layer_kernel(const set_dev T) {
   const int nb_seg = T.n_seg_slots >> 2, nb_gseg = T.n_gseg_slots >> 4;
   const int lb = blockIdx.x;
   const __amdgpu_buffer_rsrc_t xr = table_rsrc(T.x, T.x_rows);
+  // The step count moves on inside the two launches, with no launch of its own and no race: this launch reads
+  // state[0] (steps taken) and leaves the new count in the spare state[3]; the cut rows' launch, which follows it,
+  // reads state[3] and writes it to state[0].  Nobody reads, within a launch, the word that launch writes.
+  if (MODE == M_BWD_LAST_ADAM && lb == 0 && threadIdx.x == 0) T.adam_state[3] = T.adam_state[0] + 1.0f;
   if (lb < nb_seg) {
     const int4 d = reinterpret_cast<const int4 *>(T.seg_desc)[lb * 4 + wave];  // begin, end, slab row
     if (d.z >= 0) {
@@ -271,6 +315,7 @@ __global__ __launch_bounds__(256) void set_layer_kernel(const set_dev T) {
       if (total >= 0) {
         set_ctx c;
         load_set_ctx<MODE>(T, row, l, c);
+        if (MODE == M_BWD_LAST_ADAM) c.adam_t = T.adam_state[0] + 1.0f;
         f32x4 sums[4];
         walk_group_row<SCALE>(xr, T.col, T.colscale, hv, hs, total, bnd, tail, l, sums);
         set_epilogue<MODE>(T, row, l, c, sums);
@@ -285,12 +330,14 @@ template <int MODE>
 __global__ __launch_bounds__(256) void set_hub_kernel(const set_dev T) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, l = lane & 15;
   const int h = blockIdx.x * 4 + wave;
+  if (MODE == M_BWD_LAST_ADAM && blockIdx.x == 0 && threadIdx.x == 0) T.adam_state[0] = T.adam_state[3];
   if (h >= T.n_hub) return;
   const int4 d0 = reinterpret_cast<const int4 *>(T.hub_desc)[2 * h], d1 = reinterpret_cast<const int4 *>(T.hub_desc)[2 * h + 1];
   const int row = d0.x;
   const int sb[5] = {d0.y, d0.z, d0.w, d1.x, d1.y};
   set_ctx c;
   load_set_ctx<MODE>(T, row, l, c);
+  if (MODE == M_BWD_LAST_ADAM) c.adam_t = T.adam_state[3];
   const __amdgpu_buffer_rsrc_t sr = table_rsrc(T.slab, T.n_seg);
   f32x4 sums[4];
 #pragma unroll
@@ -342,6 +389,8 @@ int fill(const dg_graphset *s, int mode, set_dev &t) {
   t.n = s->n; t.n_graphs = s->n_graphs; t.n_hub = s->n_hub; t.n_seg_slots = s->n_seg_slots; t.n_gseg_slots = s->n_gseg_slots;
   t.n_rec = s->n_rec;
   t.slope = 0.f;
+  t.adam_p = t.adam_m = t.adam_v = nullptr; t.adam_state = nullptr;
+  t.lr = t.beta1 = t.beta2 = t.eps = t.weight_decay = 0.f;
   int device = 0;
   DG_HIP(hipGetDevice(&device));
   if (device != s->device)
@@ -353,7 +402,9 @@ template <int MODE>
 int launch(const dg_graphset *s, const set_dev &t, hipStream_t stream) {
   const int blocks = (s->n_seg_slots >> 2) + (s->n_gseg_slots >> 4) + ((s->n_rec + 15) >> 4);
   hipLaunchKernelGGL(set_layer_kernel<MODE>, dim3(blocks), dim3(256), 0, stream, t);
-  if (s->n_hub > 0) hipLaunchKernelGGL(set_hub_kernel<MODE>, dim3((s->n_hub + 3) >> 2), dim3(256), 0, stream, t);
+  // (with the optimizer step inside, the second launch also moves the step count on: it runs even without cut rows)
+  if (s->n_hub > 0 || MODE == M_BWD_LAST_ADAM)
+    hipLaunchKernelGGL(set_hub_kernel<MODE>, dim3(std::max((s->n_hub + 3) >> 2, 1)), dim3(256), 0, stream, t);
   DG_HIP(hipGetLastError());
   return 0;
 }
@@ -668,4 +719,20 @@ extern "C" int dg_set_layer_bwd_last(dg_graphset *set, const float *w_in, float 
   if ((rc = fill(set, M_BWD_LAST, t))) return rc;
   t.x = w_in; t.sum_first = g_out; t.slope = 1.0f;
   return launch<M_BWD_LAST>(set, t, (hipStream_t)stream);
+}
+
+extern "C" int dg_set_layer_bwd_last_adam(dg_graphset *set, const float *w_in, const float *d_first, const float *d_rest,
+                                          float *param, float *exp_avg, float *exp_avg_sq, float *state, float lr,
+                                          float beta1, float beta2, float eps, float weight_decay, int32_t d, void *stream) {
+  int rc = check_d("dg_set_layer_bwd_last_adam", set, d);
+  if (rc) return rc;
+  if (!w_in || !d_first || !d_rest || !param || !exp_avg || !exp_avg_sq || !state)
+    return dg_fail(DG_ERR_ARG, "dg_set_layer_bwd_last_adam: NULL argument");
+  if (param == w_in) return dg_fail(DG_ERR_ARG, "dg_set_layer_bwd_last_adam: the parameter table must not be the gathered table");
+  set_dev t;
+  if ((rc = fill(set, M_BWD_LAST, t))) return rc;
+  t.x = w_in; t.d_first = d_first; t.d_rest = d_rest; t.slope = 1.0f;
+  t.adam_p = param; t.adam_m = exp_avg; t.adam_v = exp_avg_sq; t.adam_state = state;
+  t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.weight_decay = weight_decay;
+  return launch<M_BWD_LAST_ADAM>(set, t, (hipStream_t)stream);
 }

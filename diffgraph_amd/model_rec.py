@@ -36,6 +36,9 @@ def pairPredict(ancEmbeds, posEmbeds, negEmbeds):  # DiffGraph-Rec/Utils/Utils.p
     return (ancEmbeds * posEmbeds).sum(-1) - (ancEmbeds * negEmbeds).sum(-1)
 
 
+APPLIED = "applied"     # HGDM.embedding_grad_parts after a backward pass that stepped the table itself
+
+
 def _same_objects(a, b) -> bool:
     return a is not None and len(a) == len(b) and all(x is y for x, y in zip(a, b))
 
@@ -95,6 +98,13 @@ class _PropagateFn(torch.autograd.Function):
                 w[g] = out
             ops.gcn_layer_bwd_batched(tasks)
         merged = None if ctx.gset is not None else model.merged_last_step()
+        step_now = getattr(model, "table_step_in_backward", None)
+        if ctx.gset is not None and step_now is not None:
+            # ... and the optimizer's step of the table inside that launch (a caller that runs backward() and step()
+            # back to back -- diffgraph_amd.train.training_step -- asks for it): the table's gradient is never written
+            step_now.step_table_in(lambda *adam: ops.set_layer_bwd_last_adam(ctx.gset, stack, d_ui, d_het, *adam))
+            model.embedding_grad_parts = APPLIED
+            return None, None
         if ctx.gset is not None:
             # the last step over the set as well: the lists BWD_MID has just walked, one output table
             g0 = torch.empty_like(ref)

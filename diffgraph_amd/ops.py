@@ -292,6 +292,23 @@ def set_layer_bwd_last(gset: GraphSet, w_in: torch.Tensor, g_out: torch.Tensor) 
 # --------------------------------------------------------------------------------------
 # diffusion
 # --------------------------------------------------------------------------------------
+def set_layer_bwd_last_adam(gset: GraphSet, w_in: torch.Tensor, d_first: torch.Tensor, d_rest: torch.Tensor, param: torch.Tensor,
+                            exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, state: torch.Tensor, lr: float, beta1: float,
+                            beta2: float, eps: float, weight_decay: float) -> None:
+    """set_layer_bwd_last with the table's Adam step in its epilogue: the gradient d_first + d_rest (once per behaviour
+    graph) + (the gathered sum) updates param / exp_avg / exp_avg_sq in place, at step count state[0] + 1, and is never
+    written; the launch moves the step count state[0] on itself."""
+    n = gset.num_nodes()
+    _stacked(w_in, "w_in", gset)
+    for nm, t in (("d_first", d_first), ("d_rest", d_rest), ("param", param), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _table(t, nm, n)
+    _vec(state, "Adam state", torch.float32, 4)
+    rc = _lib.load().dg_set_layer_bwd_last_adam(gset.handle, w_in.data_ptr(), d_first.data_ptr(), d_rest.data_ptr(), param.data_ptr(),
+                                                exp_avg.data_ptr(), exp_avg_sq.data_ptr(), state.data_ptr(), float(lr), float(beta1),
+                                                float(beta2), float(eps), float(weight_decay), DG_D, _lib.stream_ptr(param.device))
+    _lib.check(rc, "dg_set_layer_bwd_last_adam")
+
+
 class DenoiserParams:
     """Device pointers + host frequencies of one Denoise module, and its per-timestep bias table."""
 

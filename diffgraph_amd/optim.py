@@ -35,6 +35,13 @@ class Adam:
         self.table.grad = None
         self.model.embedding_grad_parts = None
 
+    def step_table_in(self, launch) -> None:
+        """For a backward pass that forms the table's gradient row by row and can update the table on the spot
+        (HGDM under `table_step_in_backward`): `launch(param, exp_avg, exp_avg_sq, state, lr, beta1, beta2, eps,
+        weight_decay)` runs it and moves the step count on; step() then leaves the table alone."""
+        launch(self.table.data, self.exp_avg, self.exp_avg_sq, self.state, self.lr, self.betas[0], self.betas[1], self.eps,
+               self.weight_decay)
+
     def step(self) -> None:
         parts = self.model.embedding_grad_parts
         if parts is None and self.table.grad is not None:
@@ -43,7 +50,7 @@ class Adam:
 
         def small():    # the denoisers' update, and the table's step count and bias corrections
             self.rest.step()
-            if parts is not None:
+            if parts is not None and not isinstance(parts, str):    # (a backward pass that stepped the table moved the count on too)
                 _lib.check(lib.dg_adam_prepare(self.state.data_ptr(), self.betas[0], self.betas[1], _lib.stream_ptr(self.table.device)),
                            "dg_adam_prepare")
 
@@ -52,7 +59,7 @@ class Adam:
             late(then=small)
         else:
             small()
-        if parts is None:
+        if parts is None or isinstance(parts, str):     # no gradient, or the backward pass has stepped the table already
             return
         parts = [p.contiguous() for p in parts]
         arr = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])

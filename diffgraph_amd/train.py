@@ -30,12 +30,16 @@ def training_step(model, opt, ancs, poss, negs, seed: torch.Tensor, draws: Optio
     # weight gradients and their Adam step -- may run beside the propagation: opt.step() joins before it returns.
     model.side_join_deferred = isinstance(opt, Adam)
     model._late_side = []            # (nothing of an abandoned step)
+    # ... and backward() is followed by step() at once: the last launch of the backward pass may update the embedding
+    # table itself, row by row as it forms the gradient (HGDM's propagation over a graph set does)
+    model.table_step_in_backward = opt if isinstance(opt, Adam) else None
     try:
         res = model.cal_loss_vector(ancs, poss, negs, **(draws or {}))
         opt.zero_grad(set_to_none=True)
         res.backward(seed)                                       # = loss.backward()
     finally:
         model.side_join_deferred = False
+        model.table_step_in_backward = None
     opt.step()
     return res
 

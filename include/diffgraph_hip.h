@@ -275,6 +275,16 @@ int dg_set_layer_bwd_top(dg_graphset *set, const float *e_saved, const float *d_
 int dg_set_layer_bwd_mid(dg_graphset *set, const float *w_in, const float *e_saved, const float *d_first,
                          const float *d_rest, float *w_out, float slope, int32_t d, void *stream);
 int dg_set_layer_bwd_last(dg_graphset *set, const float *w_in, float *g_out, int32_t d, void *stream);
+/* dg_set_layer_bwd_last with the embedding table's optimizer step in its epilogue (main.py:127-128 runs
+ * loss.backward() and opt.step() back to back): a row's gradient -- d_first + d_rest once per behaviour graph (every
+ * graph's layer sum starts from the table, Model.py:57,74) + g_out, added left to right -- goes straight into
+ * torch.optim.Adam's update of param / exp_avg / exp_avg_sq at step count state[0] + 1 and never reaches memory.
+ * Same bits as dg_set_layer_bwd_last, then dg_adam_prepare + dg_adam_step_prepared over those parts.  `state` is
+ * dg_adam_step's [4]: the call also moves its step count state[0] on by one (through the spare word state[3]; the
+ * bias corrections in state[1..2] are left as they were -- dg_adam_prepare rebuilds them from the count). */
+int dg_set_layer_bwd_last_adam(dg_graphset *set, const float *w_in, const float *d_first, const float *d_rest, float *param,
+                               float *exp_avg, float *exp_avg_sq, float *state, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int32_t d, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * a6: q_sample.  Replaces GaussianDiffusion.q_sample + _extract_into_tensor

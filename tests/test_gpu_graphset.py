@@ -145,3 +145,38 @@ def test_graph_set_refuses_what_it_cannot_walk():
         ops.set_layer_first(gset, x, torch.empty(3, n, 64, device=DEV))
     with pytest.raises(dg.DiffGraphHipError):
         ops.set_layer_first(gset, x[:-1], torch.empty(2, n, 64, device=DEV))
+
+
+@pytest.mark.parametrize("name,n_graphs,set_kw", [("tiny", 3, dict(group_max=12, seg_len=64)), ("tiny", 2, {}), ("ijcai", 4, {})])
+def test_last_backward_step_with_the_optimizer_inside(name, n_graphs, set_kw):
+    """dg_set_layer_bwd_last_adam against dg_set_layer_bwd_last followed by the table's Adam kernels over the parts
+    [d_first, d_rest x (graphs - 1), g0]: the same bits in the table, both moments and the step count, three steps in a
+    row (weight decay on in the last one)."""
+    import ctypes as C
+    from diffgraph_amd import _lib
+    wl, pairs, model, ue, ie = rec_model(name, n_graphs, **set_kw)
+    gset = model.graph_set()
+    n, G = wl.n_user + wl.n_item, n_graphs
+    gen = torch.Generator().manual_seed(3)
+    lib = _lib.load()
+    state = {k: [torch.randn(n, 64, generator=gen).to(DEV) * 0.1, torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV),
+                 torch.zeros(4, device=DEV)] for k in ("fused", "parts")}
+    state["parts"][0].copy_(state["fused"][0])
+    for step, wd in enumerate((0.0, 0.0, 0.01)):
+        w_in = torch.randn(G, n, 64, generator=gen).to(DEV)
+        d_first, d_rest = torch.randn(n, 64, generator=gen).to(DEV), torch.randn(n, 64, generator=gen).to(DEV)
+        hyper = (1e-3, 0.9, 0.999, 1e-8, wd)
+        p, m, v, st = state["fused"]
+        ops.set_layer_bwd_last_adam(gset, w_in, d_first, d_rest, p, m, v, st, *hyper)
+        p, m, v, st = state["parts"]
+        g0 = torch.empty(n, 64, device=DEV)
+        ops.set_layer_bwd_last(gset, w_in, g0)
+        parts = [d_first] + [d_rest] * (G - 1) + [g0]
+        arr = (C.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+        _lib.check(lib.dg_adam_prepare(st.data_ptr(), 0.9, 0.999, _lib.stream_ptr(p.device)), "dg_adam_prepare")
+        _lib.check(lib.dg_adam_step_prepared(p.data_ptr(), arr, len(parts), m.data_ptr(), v.data_ptr(), st.data_ptr(), p.numel(),
+                                             *hyper, _lib.stream_ptr(p.device)), "dg_adam_step_prepared")
+        torch.cuda.synchronize()
+        for a, b, what in zip(state["fused"][:3], state["parts"][:3], ("table", "exp_avg", "exp_avg_sq")):
+            assert torch.equal(a, b), (step, what)
+        assert float(state["fused"][3][0]) == float(state["parts"][3][0]) == step + 1
