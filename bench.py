@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--one-gpu-forward", default="industry", help="workload of the multi-GPU experiment (forward propagation) timed on "
                     "this one GPU as config.<name>_1gpu_edges_per_s ('' for none)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-side-overlap", action="store_true",
+                    help="keep the step's short side launches on the main stream (what running them beside the propagation buys)")
     return ap.parse_args()
 
 
@@ -139,12 +141,12 @@ def time_layers(model, timer, step, iters: int, graphs):
     row per (mode, layer)."""
     timer.records = []
     timer.enabled = True
-    model.side_overlap = False
+    overlap, model.side_overlap = model.side_overlap, False
     for _ in range(iters):
         torch.cuda._sleep(10_000_000)   # the GPU spins ~5 ms while the host queues the step: launches then run back to back,
         step()                          # and an interval holds kernel time, not the host's launch latency
     torch.cuda.synchronize()
-    model.side_overlap = True
+    model.side_overlap = overlap
     train_layers = timer.by_key()
     timer.records = []
     with torch.no_grad():
@@ -421,6 +423,8 @@ def main():
         return
     wl, graphs, model, timer, step = rec_step(workload, device)
     B = model.args.batch
+    if args.no_side_overlap:
+        model.side_overlap = False
 
     if args.no_graph:
         run = step
