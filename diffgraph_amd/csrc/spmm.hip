@@ -913,9 +913,10 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
                      graphs[k]->device, device);
     if ((t.flags & kRowsMask) != rows_sel)
       return dg_fail(DG_ERR_ARG, "layer tasks 0 and %d differ in DG_ROWS_PARTIAL_ONLY / DG_ROWS_FULL_ONLY", k);
-    if (rows_sel && (t.lds_split <= 0 || !t.partial_out || t.partial_from != t.lds_split))
-      return dg_fail(DG_ERR_ARG, "layer task %d: DG_ROWS_*_ONLY needs a graph with one side held in LDS and partial_from at "
-                     "that side's first row (%d), got partial_from %d", k, t.lds_split, t.partial_out ? t.partial_from : -1);
+    if (rows_sel && (t.lds_split <= 0 || (t.partial_out && t.partial_from != t.lds_split)))
+      return dg_fail(DG_ERR_ARG, "layer task %d: DG_ROWS_*_ONLY needs a graph with one side held in LDS and, when partial sums are "
+                     "asked for, partial_from at that side's first row (%d), got partial_from %d", k, t.lds_split,
+                     t.partial_out ? t.partial_from : -1);
   }
   const bool full_rows = rows_sel != DG_ROWS_PARTIAL_ONLY, partial_rows = rows_sel != DG_ROWS_FULL_ONLY;
   for (int k = 0; k < n_tasks; ++k) {

@@ -14,6 +14,7 @@ next one, and adds the L2-normalised activation into that graph's running sum.
 from __future__ import annotations
 
 from contextlib import contextmanager
+from dataclasses import replace
 from types import SimpleNamespace
 from typing import List, Optional
 
@@ -23,7 +24,8 @@ from torch import nn
 
 from . import ops
 from .graph import CSRGraph, GraphSet
-from ._lib import DG_ACC_REBUILD, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE
+from ._lib import (DG_ACC_REBUILD, DG_ACC_SHARED, DG_BWD_SAVED_PRESCALED, DG_D, DG_IN_PRESCALED, DG_OUT_PRESCALE,
+                   DG_ROWS_FULL_ONLY, DG_ROWS_PARTIAL_ONLY)
 from .diffusion import Denoise, GaussianDiffusion, dropout_args, dropout_rate
 from .layers import DGLLayer
 
@@ -417,10 +419,32 @@ class HGDM(nn.Module):
             hook = getattr(self, "layer_hook", None)
             if hook is not None:
                 hook("begin", l, tasks)
-            ops.gcn_layer_batched(tasks)
+            split = self._lds_split(graphs) if (last and l == 1 and not keep and len(graphs) >= 2) else 0
+            if split:
+                # Graphs with one small side held in LDS (the Industry shape): the small side's rows per graph, then
+                # the large side's rows of ALL graphs in one walk that writes `ui` and `het` directly -- e0 read once
+                # per row, no layer sum per behaviour graph for them (DG_ACC_SHARED)
+                het = sums[1] if len(graphs) == 2 else torch.empty_like(e0)
+                ops.gcn_layer_batched([replace(t, flags=t.flags | DG_ROWS_PARTIAL_ONLY) for t in tasks])
+                ops.gcn_layer_batched([replace(t, flags=t.flags | DG_ROWS_FULL_ONLY | DG_ACC_SHARED,
+                                               acc_out=sums[0] if g == 0 else het) for g, t in enumerate(tasks)])
+                if len(graphs) > 2:
+                    ops.prepare_sum_tables([t[split:] for t in sums[1:]], het[split:])()
+            else:
+                ops.gcn_layer_batched(tasks)
             if hook is not None:
                 hook("end", l, tasks)
+            if split:
+                return sums[0], het, saved
         return sums[0], ops.sum_tables(sums[1:]), saved
+
+    def _lds_split(self, graphs) -> int:
+        """The first row of the side every graph holds in LDS, when all of them do and agree on it (else 0)."""
+        kept = getattr(self, "_lds_split_of", None)
+        if kept is None or not _same_objects(kept[0], graphs):
+            splits = {int(g.schedule()["lds_split"]) for g in graphs}
+            kept = self._lds_split_of = (list(graphs), splits.pop() if len(splits) == 1 and 0 not in splits else 0)
+        return kept[1]
 
     def forward(self):
         ui, het = self.propagate(self.embedding_table)

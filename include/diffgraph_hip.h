@@ -131,7 +131,9 @@ enum { DG_ROWS_PARTIAL_ONLY = 64, DG_ROWS_FULL_ONLY = 128 };
  * (their partial sums), a call with DG_ROWS_FULL_ONLY only the rows below; the two together equal
  * one call with neither flag.  All tasks of a call carry the same choice.  Accepted for graphs
  * whose schedule keeps the two row classes in separate launches (one small side held in LDS, with
- * partial_from equal to the first row of that side); an argument error otherwise. */
+ * partial_from equal to the first row of that side); an argument error otherwise.  Without
+ * partial_out the two calls cut the layer at the same row (the first row of the side held in
+ * LDS) and the rows of the first call get the usual epilogue. */
 enum { DG_ACC_SHARED = 0x800 };
 /* With DG_ROWS_FULL_ONLY on the last layer (DG_IN_PRESCALED | DG_ACC_REBUILD, no e_out): the tasks' rows are walked
  * together, row by row through all graphs, and only two tables are written -- task 0's acc_out as usual, and ONE table

@@ -1453,3 +1453,23 @@ def test_merged_last_backward_step_equals_the_per_graph_steps():
         assert (m.merged_last_step() is not None) == merge
     assert torch.equal(grads[True][1], grads[False][1]) and torch.equal(grads[True][2], grads[False][2])
     assert_rows_close(grads[True][0], grads[False][0], rtol=2e-6, what="d e0, merged last step vs per graph")
+
+
+def test_model_inference_on_lds_graphs_walks_the_last_layer_once():
+    """HGDM.propagate without gradients on graphs with one side held in LDS: the last layer's large-side rows of all
+    graphs in one walk (DG_ACC_SHARED) -- bit for bit the sums of the task-per-graph form (the one a backward pass needs)."""
+    from types import SimpleNamespace
+    nu, ni = 9000, 37
+    inter = [dgdata.synth_interactions(nu, ni, m, seed) for m, seed in ((30000, 1), (80000, 2), (12000, 3))]
+    graphs = [dg.CSRGraph.from_bipartite(u, i, nu, ni) for (u, i) in inter]
+    handler = SimpleNamespace(userNum=nu, itemNum=ni, target_adj=graphs[0], behavior_mats=graphs[1:])
+    m = dg.rec.HGDM(handler).eval()
+    assert m.graph_set() is None and m._lds_split(graphs) == nu
+    with torch.no_grad():
+        ui, het = m.propagate(m.embedding_table)
+        ui_k, het_k, _ = m._propagate(m.embedding_table.detach(), keep=True)
+    assert torch.equal(ui, ui_k) and torch.equal(het, het_k)
+    ue, ie = m.embedding_table[:nu].detach().cpu(), m.embedding_table[nu:].detach().cpu()
+    tu, ti, hu, hi = O.rec_forward(edges_t(*inter[0], nu), [edges_t(*b, nu) for b in inter[1:]], ue, ie, 2)
+    assert_rows_close(ui, torch.cat([tu, ti]), what="lds graphs: target sums vs oracle")
+    assert_rows_close(het, torch.cat([hu, hi]), what="lds graphs: behaviour sums vs oracle")
