@@ -122,16 +122,24 @@ class _Pending:
         return self.out
 
 
-def all_gather_start(t: torch.Tensor, world: int, group=None, out: Optional[torch.Tensor] = None) -> _Pending:
+def _gather_async(t: torch.Tensor, world: int, group=None, out: Optional[torch.Tensor] = None) -> _Pending:
+    """The collective itself: one all_gather_into_tensor, enqueued only (`async_op`)."""
+    import torch.distributed as dist
+    if out is None:
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    flat = out.view((world * t.shape[0],) + tuple(t.shape[1:]))    # the concatenated form: every backend takes it
+    return _Pending(out, dist.all_gather_into_tensor(flat, t.contiguous(), group=group, async_op=True))
+
+
+def all_gather_start(t: torch.Tensor, world: int, group=None, out: Optional[torch.Tensor] = None,
+                     always_collective: bool = False) -> _Pending:
     """As all_gather_stack (into `out` [world, ...] if given), but on GPU tensors over RCCL the collective is only
     enqueued (on the communicator's own stream, after everything already enqueued on the current stream): kernels
     launched before `wait()` run beside it."""
     import torch.distributed as dist
-    if world > 1 and (t.is_cuda != (dist.get_backend(group) == "gloo")):   # RCCL on GPU tensors, gloo on host tensors
-        if out is None:
-            out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        flat = out.view((world * t.shape[0],) + tuple(t.shape[1:]))    # the concatenated form: every backend takes it
-        return _Pending(out, dist.all_gather_into_tensor(flat, t.contiguous(), group=group, async_op=True))
+    # RCCL on GPU tensors, gloo on host tensors (always_collective: a one-rank job too goes through the collective)
+    if (world > 1 or always_collective) and (t.is_cuda != (dist.get_backend(group) == "gloo")):
+        return _gather_async(t, world, group, out)
     res = all_gather_stack(t, world, group)
     if out is None:
         return _Pending(res)
@@ -244,12 +252,13 @@ class ShardedRecPropagation:
         # ... and then the last layer's user rows of all graphs in one walk that writes `ui` and `het` directly
         self.sum_in_layer = n_layers == 2 and len(self.graphs) >= 2 and getattr(backend, "sums_in_layer", False)
         self.reuse_buffers = reuse_buffers
+        self.always_collective = False    # True: a one-rank job issues the (trivial) collective as well
         self._programs = {}
 
     def _exchange(self, partials: torch.Tensor, out: torch.Tensor) -> _Pending:
         """[G, n_item, 64] on every rank -> out [world, G, n_item, 64] (partial sums in rank order), valid after
         `.wait()`."""
-        return all_gather_start(partials, self.world, self.group, out)
+        return all_gather_start(partials, self.world, self.group, out, self.always_collective)
 
     def _program(self, e0: torch.Tensor):
         """Allocates the buffers of a forward pass over `e0` and prepares its launches.
