@@ -539,15 +539,23 @@ __global__ __launch_bounds__(512) void lds_sum_rows_kernel(const dg_task_batch b
 // Rows [lds_split, n) of the same graphs (the small side; each has neighbours all over the large
 // side).  A 1024-thread workgroup walks a contiguous run of windows of DG_WIN_ROWS large-side rows:
 // it copies the window's table rows (times their source norm unless already scaled) and the
-// window's entry blocks into LDS -- the next window's are requested before the current one is
-// summed -- and every 16-lane group adds, for each part it owns (dg_csr::wblocks), the window
-// rows on that part's list: one ds_read_b32 gives four list entries, four ds_read_b128 the rows.
+// window's entry blocks into LDS and every 16-lane group adds, for each part it owns
+// (dg_csr::wblocks), the window rows on that part's list: one ds_read_b32 gives four list entries,
+// four ds_read_b128 the rows.  The windows alternate between two LDS buffers (all 160 KB of the
+// CU): while window w is summed out of one, window w + 1 -- requested from memory one window
+// earlier -- is written into the other and window w + 2 is requested; one barrier per window.
 // The running sums of a group's (up to 8) parts stay in registers for the whole run and go to
 // the slab at the end, one slab row per (part, workgroup); hub_reduce_kernel adds a row's slab
 // rows in order.  All orders are fixed, so results are reproducible run to run.
+constexpr int kWinTabF4 = (DG_WIN_ROWS + 1) * 16;   // float4 of one staged window (the last row is zeros)
+constexpr size_t kWinLds = 2 * ((size_t)DG_WIN_ENT_DWORDS * 4 + (size_t)kWinTabF4 * 16);
+static_assert(kWinLds <= 160 * 1024, "two staged windows and their entry blocks fill the CU's LDS exactly");
 __global__ __launch_bounds__(1024) void window_rows_kernel(const dg_task_batch batch) {
-  extern __shared__ f32x4 tab[];  // [DG_WIN_ROWS + 1][16] rows (the last is zeros), then the entry blocks
-  uint32_t *ebuf = reinterpret_cast<uint32_t *>(tab + (DG_WIN_ROWS + 1) * 16);
+  // [2][DG_WIN_ENT_DWORDS] entry blocks, then [2][DG_WIN_ROWS + 1][16] rows: the dword read past the end of an
+  // entry buffer (see below) then lies inside the allocation
+  extern __shared__ f32x4 win_lds[];
+  uint32_t *ebuf = reinterpret_cast<uint32_t *>(win_lds);
+  f32x4 *tab = win_lds + 2 * DG_WIN_ENT_DWORDS / 4;
   int ti = 0;
   for (int k = 0; k < batch.n_tasks; ++k)
     if (batch.t[k].win_blk_count > 0 && (int)blockIdx.x >= batch.t[k].win_blk_begin) ti = k;
@@ -558,14 +566,13 @@ __global__ __launch_bounds__(1024) void window_rows_kernel(const dg_task_batch b
   const int split = T.lds_split;
   const bool scale = !(T.flags & DG_IN_PRESCALED);
   const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-  const f32x4 *t = tab + l;
 
   f32x4 acc[DG_WIN_SLOTS];
 #pragma unroll
   for (int k = 0; k < DG_WIN_SLOTS; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // the next window, on its way while the current one is summed: its rows (4 float4 per thread) and
-  // their norms, 4 dwords of its entry blocks, and where this group's block starts among them
+  // a window on its way from memory: its rows (4 float4 per thread) and their norms, 4 dwords of its entry
+  // blocks, and where this group's block starts among them
   f32x4 pre[4];
   float ps[4];
   u32x4 pent;
@@ -586,15 +593,28 @@ __global__ __launch_bounds__(1024) void window_rows_kernel(const dg_task_batch b
     if (4 * threadIdx.x < o1 - o0) pent = reinterpret_cast<const u32x4 *>(T.wblocks + o0)[threadIdx.x];
     goff_next = (int)(T.woff[w * DG_WIN_GROUPS + g] - o0);
   };
-  if (w0 < w1) fetch(w0);
-  for (int w = w0; w < w1; ++w) {
-    __syncthreads();  // every group is done with the previous window
+  auto stage = [&](int buf) {   // the fetched window -> LDS buffer `buf`
 #pragma unroll
-    for (int p = 0; p < 4; ++p) tab[threadIdx.x + 1024 * p] = pre[p] * ps[p];  // row 255 gets zeros
-    reinterpret_cast<u32x4 *>(ebuf)[threadIdx.x] = pent;
-    const uint32_t *e = ebuf + goff_next;
+    for (int p = 0; p < 4; ++p) tab[buf * kWinTabF4 + threadIdx.x + 1024 * p] = pre[p] * ps[p];  // row 255 gets zeros
+    reinterpret_cast<u32x4 *>(ebuf + buf * DG_WIN_ENT_DWORDS)[threadIdx.x] = pent;
+  };
+  int goff = 0;
+  if (w0 < w1) {   // (a workgroup whose run is empty still writes its -- zero -- slab rows below)
+    fetch(w0);
+    stage(0);
+    goff = goff_next;
+    if (w0 + 1 < w1) fetch(w0 + 1);
     __syncthreads();
-    if (w + 1 < w1) fetch(w + 1);
+  }
+  for (int w = w0; w < w1; ++w) {
+    const int cur = (w - w0) & 1;
+    const f32x4 *t = tab + cur * kWinTabF4 + l;
+    const uint32_t *e = ebuf + cur * DG_WIN_ENT_DWORDS + goff;
+    if (w + 1 < w1) {   // the other buffer was last read a barrier ago
+      stage(cur ^ 1);
+      goff = goff_next;
+      if (w + 2 < w1) fetch(w + 2);
+    }
     const unsigned h0 = e[0], h1 = e[1];
     unsigned dn = e[DG_WIN_HDR];  // the entry dword after the one being summed is always on its way
     e += DG_WIN_HDR + 1;
@@ -603,12 +623,13 @@ __global__ __launch_bounds__(1024) void window_rows_kernel(const dg_task_batch b
       const int c = ((k < 4 ? h0 : h1) >> (8 * (k & 3))) & 0xff;
       for (int j = 0; j < c; ++j) {
         const unsigned d = dn;
-        dn = *e++;  // at the end of the last block this reads the spare dword behind the buffer
+        dn = *e++;  // at the end of the last block this reads the dword behind the buffer
         const f32x4 v0 = t[(d & 0xffu) * 16], v1 = t[(d >> 8 & 0xffu) * 16];
         const f32x4 v2 = t[(d >> 16 & 0xffu) * 16], v3 = t[(d >> 24) * 16];
         acc[k] += v0; acc[k] += v1; acc[k] += v2; acc[k] += v3;
       }
     }
+    __syncthreads();  // this window has been read by every group, the next one is in place
   }
 #pragma unroll
   for (int k = 0; k < DG_WIN_SLOTS; ++k) {
@@ -1035,10 +1056,9 @@ int launch_batch(dg_task_batch &batch, const dg_graph *const *graphs, hipStream_
     hipLaunchKernelGGL(lds_rows_kernel, dim3(lds_blocks), dim3(1024), lds_bytes, stream, batch);
   }
   if (win_blocks > 0 && partial_rows) {
-    constexpr size_t win_lds = (DG_WIN_ROWS + 1) * DG_D * sizeof(float) + DG_WIN_ENT_DWORDS * 4 + 16;
     static std::atomic<uint64_t> win_opted{0};
-    DG_HIP(dg_lds_opt_in(reinterpret_cast<const void *>(window_rows_kernel), (int)win_lds, win_opted));
-    hipLaunchKernelGGL(window_rows_kernel, dim3(win_blocks), dim3(1024), win_lds, stream, batch);
+    DG_HIP(dg_lds_opt_in(reinterpret_cast<const void *>(window_rows_kernel), (int)kWinLds, win_opted));
+    hipLaunchKernelGGL(window_rows_kernel, dim3(win_blocks), dim3(1024), kWinLds, stream, batch);
   }
   // (under DG_ROWS_*_ONLY no task has gcn_layer_kernel rows, and every hub row is a partial-sum row)
   if (blocks > 0) hipLaunchKernelGGL(gcn_layer_kernel, dim3(blocks), dim3(256), 0, stream, batch);
