@@ -1000,11 +1000,12 @@ def test_sharded_lds_graphs_split_layer_calls():
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
 
 
-def test_shared_layer_sum_flag_is_checked():
-    """DG_ACC_SHARED: only with DG_ROWS_FULL_ONLY on the last layer of graphs with one side in LDS, tasks 1.. naming one table."""
+@pytest.mark.parametrize("nu,ni", [(3000, 20), (1300, 7), (40000, 383)])
+def test_shared_layer_sum_flag_is_checked(nu, ni):
+    """DG_ACC_SHARED: only with DG_ROWS_FULL_ONLY on the last layer of graphs with one side in LDS, tasks 1.. naming one
+    table -- from less than one workgroup's worth of rows to the largest side LDS holds."""
     from diffgraph_amd._lib import (DG_ACC_REBUILD, DG_ACC_SHARED, DG_IN_PRESCALED, DG_ROWS_FULL_ONLY, DiffGraphHipError)
-    nu, ni = 3000, 20
-    gs = [dg.CSRGraph.from_bipartite(*dgdata.synth_interactions(nu, ni, 9000, seed), nu, ni) for seed in (1, 2, 3, 4)]
+    gs = [dg.CSRGraph.from_bipartite(*dgdata.synth_interactions(nu, ni, 3 * nu, seed), nu, ni) for seed in (1, 2, 3, 4)]
     assert all(g.schedule()["lds_split"] == nu for g in gs)
     n = nu + ni
     e0, x = dev(torch.randn(n, 64)), [dev(torch.randn(n, 64)) for _ in gs]
