@@ -20,6 +20,7 @@
 #include "dg_wgrad.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -274,6 +275,143 @@ __global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch bat
     ss += __shfl_xor(ss, 32);
     if (valid && h == 0) T.row_loss[row] = T.loss_w[t] * (double)(ss * (1.0f / DG_D));
   }
+}
+
+// ---- the reverse loop on the bf16 matrix instruction, fp32 values cut three ways -------------------------------
+// v_mfma_f32_32x32x16_bf16 runs at sixteen times the rate of the exact-fp32 instruction.  An fp32 value is the sum of
+// three bf16 numbers EXACTLY (its 24 significand bits in three runs of eight: hi, mid, lo), a product of two bf16
+// numbers is exact in fp32, and the accumulator is fp32: with w = wh + wm + wl and x = xh + xm + xl the six products
+//     wh xh + wh xm + wm xh + wm xm + wh xl + wl xh
+// leave out only terms below 2^-24 of |w x| -- the size of ONE fp32 rounding -- so a contraction carried out this way
+// is as close to the exact sum as the fp32 instruction's own result (not the same bits: the roundings fall
+// elsewhere), at 6/16 of its matrix cycles.  The loop's 400 contractions per row are where that pays.
+// Layout: the accumulator layout of the 32x32 instructions is the same for both types (row of the tile on the lane,
+// feature 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of a 32-feature block in register r), and the B operand of the bf16
+// instruction takes eight consecutive k per lane half: registers 8p .. 8p+7 of a block ARE such a run -- chunk
+// (block tau, pair p) carries the sixteen features 32 tau + 16 p .. + 15, lane half h holding
+// 32 tau + 8 (2p + e / 4) + 4 h + e % 4 as its e-th -- so the activations still never leave the lane; the weight
+// images in LDS are laid out to match (bf16x8 per lane, plane, chunk and output half).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+struct bf3 {
+  u32x4_t hi, mid, lo;   // eight bf16 each, two per dword (element 2k in the low half)
+};
+
+// eight fp32 -> their three bf16 planes (hi + mid + lo == x up to the bits below the 24th)
+// (v_cvt_pk_bf16_f32 rounds two values to nearest-even bf16 in one instruction; the remainders x - hi and
+// (x - hi) - mid are exact in fp32, and rounding to nearest leaves them at most eight significant bits each)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+__device__ __forceinline__ bf3 split8(const float (&x)[8]) {
+  bf3 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a = x[2 * k], b = x[2 * k + 1];
+    const unsigned h = pack_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    const unsigned m = pack_bf16(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    o.hi[k] = h;
+    o.mid[k] = m;
+    o.lo[k] = pack_bf16(sa, sb);
+  }
+  return o;
+}
+
+constexpr int kB3Image = 2 * 4 * 3 * 64;   // u32x4 per 64x64 matrix: [to][chunk][plane][lane]
+
+// acc[to] += W[32 to .. + 32][:] . act  with W as a three-plane image and act in the accumulator layout
+__device__ __forceinline__ void contract64_b3(const u32x4_t *__restrict__ img, int lane, const f32x16 (&act)[2], f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = act[tau][8 * p + e];
+      const bf3 b = split8(x);
+      const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, b.hi), bm = __builtin_bit_cast(bf16x8_t, b.mid),
+                     bl = __builtin_bit_cast(bf16x8_t, b.lo);
+      const int chunk = 2 * tau + p;
+#pragma unroll
+      for (int to = 0; to < 2; ++to) {
+        const u32x4_t *a = img + ((to * 4 + chunk) * 3) * 64 + lane;
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, a[0]), am = __builtin_bit_cast(bf16x8_t, a[64]),
+                       al = __builtin_bit_cast(bf16x8_t, a[128]);
+        // smallest terms first
+        acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[to], 0, 0, 0);
+        acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[to], 0, 0, 0);
+        acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[to], 0, 0, 0);
+        acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[to], 0, 0, 0);
+        acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[to], 0, 0, 0);
+        acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[to], 0, 0, 0);
+      }
+    }
+}
+
+// Stages the two weight matrices of a denoiser as three-plane images: [matrix][to][chunk][plane][lane].
+__device__ __forceinline__ void stage_b3(u32x4_t *__restrict__ img, const float *__restrict__ w_in, const float *__restrict__ w_out) {
+  for (int idx = threadIdx.x; idx < 2 * 2 * 4 * 64; idx += blockDim.x) {
+    const int ln = idx & 63, chunk = (idx >> 6) & 3, to = (idx >> 8) & 1, m = idx >> 9;
+    const int tau = chunk >> 1, p = chunk & 1, i = ln & 31, kh = ln >> 5;
+    const float *row = m == 0 ? w_in + (32 * to + i) * 72 : w_out + (32 * to + i) * 64;
+    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(row + 32 * tau + 8 * (2 * p) + 4 * kh);
+    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(row + 32 * tau + 8 * (2 * p + 1) + 4 * kh);
+    const float x[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const bf3 s3 = split8(x);
+    u32x4_t *dst = img + m * kB3Image + ((to * 4 + chunk) * 3) * 64 + ln;
+    dst[0] = s3.hi; dst[64] = s3.mid; dst[128] = s3.lo;
+  }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void psample_b3_kernel(const dn_batch batch) {
+  __shared__ u32x4_t img[2 * kB3Image];   // 48 KiB
+  const int b = blockIdx.x;
+  int ti_ = 0;
+  for (int k = 1; k < batch.n_tasks; ++k)
+    if (b >= batch.t[k].blk_begin) ti_ = k;
+  const dn_task &T = batch.t[ti_];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int64_t row = ((int64_t)(b - T.blk_begin) * kWavesPerBlock + wave) * kRowsPerWave + j;
+  const bool valid = row < T.n;
+  const bool norm = T.norm != 0;
+  f32x16 xs[2];
+  load_tile(T.x + row * DG_D, h, valid, xs);
+  stage_b3(img, T.w_in, T.w_out);
+  __syncthreads();
+  for (int step = T.n_steps - 1; step >= 0; --step) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // (keeps the weight operands out of loop-invariant registers)
+    f32x16 xn[2] = {xs[0], xs[1]};
+    if (norm) {
+      float ss = 0.f;
+#pragma unroll
+      for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ss += xs[tau][r] * xs[tau][r];
+      ss += __shfl_xor(ss, 32);
+      const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+      xn[0] = xs[0] * inv;
+      xn[1] = xs[1] * inv;
+    }
+    f32x16 hid[2], out[2];
+    load_tile(T.time_bias + step * DG_D, h, true, hid);
+    contract64_b3(img, ln, xn, hid);
+#pragma unroll
+    for (int tau = 0; tau < 2; ++tau)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[tau][r] = tanh_short(hid[tau][r]);
+    load_tile(T.b_out, h, true, out);
+    contract64_b3(img + kB3Image, ln, hid, out);
+    const float c1 = T.coef1[step], c2 = T.coef2[step];
+    xs[0] = c1 * out[0] + c2 * xs[0];  // model_mean (Model.py:323)
+    xs[1] = c1 * out[1] + c2 * xs[1];
+  }
+  store_tile(T.out + row * DG_D, h, valid, xs);
 }
 
 // Backward of training_losses2 for a 32-row tile per wavefront: recomputes the forward
@@ -549,6 +687,13 @@ int check_denoiser(const char *who, const dg_denoiser *dn, const float *time_bia
   return 0;
 }
 
+// DG_PSAMPLE_FP32=1: the reverse loop on the exact-fp32 matrix instruction (the form before the bf16 three-way split; kept
+// for A/B runs and as the reference the split form is tested against)
+bool psample_fp32() {
+  const char *e = getenv("DG_PSAMPLE_FP32");   // (read at every launch: a test compares the two forms in one process)
+  return e && e[0] == '1';
+}
+
 template <int MODE>
 int launch_one(dn_task &t, hipStream_t stream) {
   if (t.n <= 0) return 0;
@@ -557,7 +702,8 @@ int launch_one(dn_task &t, hipStream_t stream) {
   for (int k = 0; k < kDnMaxTasks; ++k) batch.t[k] = t;
   batch.n_tasks = 1;
   const int64_t blocks = (t.n + kRowsPerBlock - 1) / kRowsPerBlock;
-  hipLaunchKernelGGL(denoise_kernel<MODE>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, batch);
+  if (MODE == MODE_PSAMPLE && !psample_fp32()) hipLaunchKernelGGL(psample_b3_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, batch);
+  else hipLaunchKernelGGL(denoise_kernel<MODE>, dim3((unsigned)blocks), dim3(kThreads), 0, stream, batch);
   DG_HIP(hipGetLastError());
   return 0;
 }
@@ -686,7 +832,8 @@ extern "C" int dg_p_sample_loop_batched(const dg_psample_task *tasks, int32_t n_
   }
   if (batch.n_tasks == 0) return 0;
   for (int k = batch.n_tasks; k < kDnMaxTasks; ++k) batch.t[k] = batch.t[0];
-  hipLaunchKernelGGL(denoise_kernel<MODE_PSAMPLE>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, batch);
+  if (psample_fp32()) hipLaunchKernelGGL(denoise_kernel<MODE_PSAMPLE>, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, batch);
+  else hipLaunchKernelGGL(psample_b3_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, batch);
   DG_HIP(hipGetLastError());
   return 0;
 }

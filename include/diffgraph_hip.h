@@ -334,7 +334,11 @@ int dg_denoise_fwd_train(const dg_denoiser *dn, const float *time_bias, int32_t 
  *     x <- coef1[i]*Denoise(x, i) + coef2[i]*x
  * run entirely in registers, one launch.  coef1/coef2: DEVICE fp32 tables (posterior mean
  * coefficients cast to fp32).  x_T is the caller's job (steps==0 -> x_start itself;
- * otherwise dg_q_sample first).  x_T and x_0 may alias. */
+ * otherwise dg_q_sample first).  x_T and x_0 may alias.
+ * The contractions run on the bf16 matrix instruction with every fp32 value cut into three
+ * bf16 numbers (six products per fp32 product: what is left out is below one fp32 rounding),
+ * or, with DG_PSAMPLE_FP32=1 in the environment, on the exact-fp32 matrix instruction; the
+ * two forms agree to a few 1e-7 of a row's largest entry after all steps. */
 int dg_p_sample_loop(const dg_denoiser *dn, const float *time_bias, const float *coef1,
                      const float *coef2, int32_t n_steps, const float *x_T, int64_t n, int32_t d,
                      float *x_0, void *stream);
