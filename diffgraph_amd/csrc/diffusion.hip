@@ -160,8 +160,9 @@ __device__ __forceinline__ void drop_tile(const dn_task &T, int64_t row, int h, 
 
 // tanh on the hardware's exp2 and reciprocal (1 ulp each): 1 - 2 / (e^{2|x|} + 1) from |x| = 1/4 on, the odd series
 // below (where the first form would cancel); within 5e-7 of tanhf, relative, at a fifth of its instructions.  For
-// the single-step kernels, whose wavefronts wait on it; the reverse loop keeps tanhf (its time is the matrix
-// instructions' chain: the short form measured no faster there).
+// the single-step kernels, whose wavefronts wait on it, and for the reverse loop on the bf16 instruction, whose time
+// is the vector unit's; the reverse loop on the fp32 instruction keeps tanhf (its time is the matrix instructions'
+// chain: the short form measured no faster there).
 __device__ __forceinline__ float tanh_short(float x) {
   const float ax = fabsf(x), x2 = ax * ax;
   const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);      // e^{2|x|}
