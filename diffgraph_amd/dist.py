@@ -20,6 +20,8 @@ CPU with torch.distributed's gloo backend; the product backend is HipBackend (HI
 from __future__ import annotations
 
 import json
+import os
+import sys
 import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -342,6 +344,28 @@ class ShardedRecPropagation:
         return prog[1]
 
 
+    def capture(self, e0: torch.Tensor):
+        """Records one forward pass over `e0` -- its prepared launches and its exchanges -- as a HIP graph (needs
+        `reuse_buffers`: the recording holds the buffers' addresses).  Returns (graph, (ui, het)): `graph.replay()`
+        refills the two tables.  Every rank must record, and later replay, the same number of times: the exchanges
+        are part of the recording.  (RCCL's collectives can be recorded once the communicator has run one eagerly,
+        which the two passes before the recording see to; `thread_local`: the communicator's watchdog thread polls
+        its events while this thread records.)"""
+        if not self.reuse_buffers:
+            raise ValueError("capture() records addresses: construct with reuse_buffers=True")
+        for _ in range(2):
+            self.forward(e0)
+        torch.cuda.synchronize(e0.device)
+        hook, self.hook = self.hook, None
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out = self.forward(e0)
+        finally:
+            self.hook = hook
+        return graph, out
+
+
 # --------------------------------------------------------------------------------------
 # bench.py leg for --gpus N > 1 (and for --workload industry at N = 1)
 # --------------------------------------------------------------------------------------
@@ -404,12 +428,25 @@ def bench_sharded(args, rank: int, world: int, device, backend=None) -> Optional
             dist.barrier()
             device_sync()
 
+    def recorded(p, table):
+        """The forward pass as a replayable HIP graph where that is on offer (GPU, user-row shards, not switched off
+        with DG_SHARD_GRAPH=0), else the eager call; a recording that fails falls back to the eager call."""
+        if on_gpu and hasattr(p, "capture") and os.environ.get("DG_SHARD_GRAPH", "1") != "0":
+            try:
+                graph, res = p.capture(table)
+                return (lambda: (graph.replay(), res)[1]), True
+            except Exception as exc:       # noqa: BLE001 -- whatever the runtime or the communicator objects to
+                print(f"[bench_sharded] forward pass not recorded as a graph ({exc!r}); running it eagerly", file=sys.stderr)
+                device_sync()
+        return (lambda: p.forward(table)), False
+    run, as_graph = recorded(prop, e0)
+
     for _ in range(args.warmup):
-        prop.forward(e0)
+        run()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = prop.forward(e0)
+        out = run()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -449,14 +486,15 @@ def bench_sharded(args, rank: int, world: int, device, backend=None) -> Optional
     # scaling of this line can be read without a second run.
     single = None
     if world > 1 and rank == 0:
-        del prop, out
+        del prop, out, run
         p1, e1 = make(0, 1)
+        run1, _ = recorded(p1, e1)
         for _ in range(max(2, args.warmup // 2)):
-            p1.forward(e1)
+            run1()
         device_sync()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            p1.forward(e1)
+            run1()
         device_sync()
         single = L * sum(nnz) * args.steps / (time.perf_counter() - t1)
 
@@ -478,7 +516,8 @@ def bench_sharded(args, rank: int, world: int, device, backend=None) -> Optional
                                    "`same_workload_1gpu_edges_per_s` of this line (measured by rank 0 in this run) or "
                                    "`industry_1gpu_edges_per_s` of the default one-GPU run -- NOT the `value` of that run, "
                                    "which times a Tmall training step",
-                       "parallelism": f"row blocks x{world}" if row_blocks else f"user-row shards x{world}"},
+                       "parallelism": f"row blocks x{world}" if row_blocks else f"user-row shards x{world}",
+                       "replayed_as_hip_graph": as_graph},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": "one sharded propagation layer on rank 0 (propagation kernels + "
                          "exchange + partial_finalize_kernel; user-row shards: a forward pass / its layers)",

@@ -54,6 +54,19 @@ for _ in range(3):
 torch.cuda.synchronize()
 assert torch.equal(ui, want[0]) and torch.equal(het, want[1])
 print("RCCL-OK sharded forward with the collective")
+
+# ... and the same pass, collective included, recorded as a HIP graph and replayed over a changed table
+graph, (gui, ghet) = prop.capture(e0)
+e0.mul_(1.5)
+want = [t.clone() for t in plain.forward(e0)]
+for _ in range(3):
+    gui.fill_(float("nan"))
+    ghet.fill_(float("nan"))
+    graph.replay()
+torch.cuda.synchronize()
+assert torch.equal(gui, want[0]) and torch.equal(ghet, want[1])
+del graph
+print("RCCL-OK sharded forward recorded as a graph")
 dist.destroy_process_group()
 
 # 2. dg_allgather_rows on a communicator made with the RCCL the library resolves (the process's, else librccl.so)

@@ -22,5 +22,5 @@ def test_rccl_call_sites_on_a_single_rank_communicator():
     if res.returncode == 3:
         pytest.skip("no RCCL communicator on this box: " + res.stdout.strip().splitlines()[-1])
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
-    for what in ("torch.distributed", "sharded forward", "dg_allgather_rows"):
+    for what in ("torch.distributed", "sharded forward with", "sharded forward recorded as a graph", "dg_allgather_rows"):
         assert "RCCL-OK " + what in res.stdout, res.stdout

@@ -62,8 +62,19 @@ def main():
             b.record()
             torch.cuda.synchronize()
             evs.append(a.elapsed_time(b))
+        # the same pass recorded as a HIP graph (stand-in exchange included) and replayed
+        graph, _ = p.capture(e0)
+        for _ in range(5):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            graph.replay()
+        torch.cuda.synchronize()
+        t_graph = time.perf_counter() - t0
         print(f"W={w}: users/rank {p.n_loc}  wall/forward {t_all / n * 1e3:.3f} ms  host enqueue {t_enq / n * 1e3:.3f} ms  "
-              f"events (sync before each) min {min(evs):.3f} med {sorted(evs)[5]:.3f} ms   ideal {1.446 / w:.3f} ms", flush=True)
+              f"events (sync before each) min {min(evs):.3f} med {sorted(evs)[5]:.3f} ms   ideal {1.446 / w:.3f} ms   "
+              f"replayed as a graph: wall/forward {t_graph / n * 1e3:.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
