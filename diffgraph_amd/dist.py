@@ -431,7 +431,9 @@ def bench_sharded(args, rank: int, world: int, device, backend=None) -> Optional
     def recorded(p, table):
         """The forward pass as a replayable HIP graph where that is on offer (GPU, user-row shards, not switched off
         with DG_SHARD_GRAPH=0), else the eager call; a recording that fails falls back to the eager call."""
-        if on_gpu and hasattr(p, "capture") and os.environ.get("DG_SHARD_GRAPH", "1") != "0":
+        # (over gloo -- the one-GPU rehearsal of several ranks -- the exchange goes through host memory: nothing to record)
+        rccl = p.world == 1 or dist.get_backend(p.group) == "nccl"
+        if on_gpu and rccl and hasattr(p, "capture") and os.environ.get("DG_SHARD_GRAPH", "1") != "0":
             try:
                 graph, res = p.capture(table)
                 return (lambda: (graph.replay(), res)[1]), True
