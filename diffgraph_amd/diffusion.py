@@ -13,7 +13,11 @@ Differences a caller can see:
     launches).  Any other `--dims` list or `--d_emb_size` (params.py:32-33) runs layer by layer: every nn.Linear
     through the HIP dense-layer kernels (dg_linear_fwd / dg_linear_wgrad, csrc/linear.hip), the elementwise steps
     between them (normalise, dropout, tanh, the loss) as torch device ops under autograd.  Correct for every
-    configuration the reference accepts at latdim 64; only the default shape is tuned.
+    configuration the reference accepts at latdim <= 64; only the default shape is tuned.
+  * `--latdim` below 64 (params.py:14): the embedding tables stay 64 floats wide with zeros from column latdim on
+    (the propagation, the loss head and the evaluation kernels are built for that width, and zero columns change
+    none of their sums); a denoiser of in_dims[0] = latdim takes such rows, works on their first latdim columns layer
+    by layer and returns rows of the width it was given.
 """
 from __future__ import annotations
 
@@ -53,10 +57,11 @@ class Denoise(nn.Module):
     def __init__(self, in_dims, out_dims, emb_size, norm=False, dropout=0.5):
         super().__init__()
         in_dims, out_dims = list(in_dims), list(out_dims)
-        if len(in_dims) < 2 or len(out_dims) < 2 or in_dims[0] != DG_D or out_dims[-1] != DG_D or emb_size < 1:
-            raise NotImplementedError(f"the embedding tables are {DG_D} wide (latdim={DG_D}): a denoiser takes and returns "
-                                      f"rows of that width, got in_dims {in_dims}, out_dims {out_dims}")
+        if len(in_dims) < 2 or len(out_dims) < 2 or not 1 <= in_dims[0] <= DG_D or out_dims[-1] != in_dims[0] or emb_size < 1:
+            raise NotImplementedError(f"the embedding tables are {DG_D} wide: a denoiser takes and returns rows of one width "
+                                      f"(latdim) of at most {DG_D}, got in_dims {in_dims}, out_dims {out_dims}")
         self.in_dims, self.out_dims = in_dims, out_dims
+        self.width = in_dims[0]             # latdim: the columns of a row that carry values
         self.time_emb_dim = emb_size
         self.norm = norm
         self.fused = in_dims == [DG_D, DG_D] and out_dims == [DG_D, DG_D] and emb_size == 8
@@ -105,7 +110,14 @@ class Denoise(nn.Module):
         return ops.denoise_fwd(p, x.contiguous(), timesteps, n_steps)
 
     def forward_layers(self, x, timesteps, mess_dropout=True, keep_mask=None):
-        """Model.py:214-234 layer by layer, differentiable: the Linear layers in the HIP dense-layer kernels."""
+        """Model.py:214-234 layer by layer, differentiable: the Linear layers in the HIP dense-layer kernels.  Rows wider
+        than latdim (the 64-wide tables of a narrower model) are cut to their first latdim columns and the result is
+        padded back with zeros."""
+        wide = x.shape[1]
+        if wide != self.width:
+            x = x[:, : self.width]
+            if keep_mask is not None:
+                keep_mask = keep_mask[:, : self.width]
         E = self.time_emb_dim
         half = E // 2
         freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32, device=x.device) / half)
@@ -128,7 +140,7 @@ class Denoise(nn.Module):
             h = _LinearFn.apply(h, layer.weight, layer.bias)
             if i != len(self.out_layers) - 1:
                 h = torch.tanh(h)
-        return h
+        return h if wide == self.width else torch.nn.functional.pad(h, (0, wide - self.width))
 
 
 def dropout_rate(models) -> float:
@@ -251,9 +263,13 @@ class GaussianDiffusion(nn.Module):
     def q_sample(self, x_start, t, noise=None):  # Model.py:302-305
         if noise is None:
             noise = torch.randn_like(x_start)
-        dev = x_start.device
-        return ops.q_sample(x_start.contiguous(), noise.contiguous(), t, self._dev("sqrt_alphas_cumprod", dev),
-                            self._dev("sqrt_one_minus_alphas_cumprod", dev))
+        dev, wide = x_start.device, x_start.shape[1]
+        if wide < DG_D:      # rows of a narrower latent space: through the 64-wide kernel with zeros behind them
+            pad = lambda v: torch.nn.functional.pad(v, (0, DG_D - wide))
+            x_start, noise = pad(x_start), pad(noise)
+        out = ops.q_sample(x_start.contiguous(), noise.contiguous(), t, self._dev("sqrt_alphas_cumprod", dev),
+                           self._dev("sqrt_one_minus_alphas_cumprod", dev))
+        return out if wide >= DG_D else out[:, :wide]
 
     def p_mean_variance(self, model, x, t):  # Model.py:314-325
         model.n_steps = self.steps
@@ -280,13 +296,14 @@ class GaussianDiffusion(nn.Module):
 
     def _p_sample_layers(self, model, x_t):
         """The reverse loop of Model.py:293-300 step by step (a denoiser outside the fused kernels' shape)."""
-        dev = x_t.device
+        dev, wide = x_t.device, x_t.shape[1]
         c1, c2 = self._dev("posterior_mean_coef1", dev), self._dev("posterior_mean_coef2", dev)
         with torch.no_grad():
+            x_t = x_t[:, : model.width]
             for i in range(self.steps - 1, -1, -1):
                 t = torch.full((x_t.shape[0],), i, dtype=torch.long, device=dev)
                 x_t = c1[i] * model.forward_layers(x_t, t, False) + c2[i] * x_t        # model_mean (Model.py:323)
-        return x_t
+        return x_t if wide == model.width else torch.nn.functional.pad(x_t, (0, wide - model.width))
 
     def p_sample_many(self, pairs, steps, noises=None):
         """p_sample for several (model, x_start) pairs in one fused launch (HGDM.predict runs the user and
@@ -347,13 +364,16 @@ class GaussianDiffusion(nn.Module):
     def _training_losses_layers(self, model, targetEmbeds, x_start, ts, noise, keep_mask):
         """Model.py:348-365 for a denoiser outside the fused kernels' shape: q_sample, the model layer by layer, the
         SNR-weighted mean square -- differentiable torch ops round the HIP dense layers."""
-        dev = x_start.device
-        x_t = x_start
+        dev, wide, L = x_start.device, x_start.shape[1], model.width
+        # (rows wider than latdim: everything below is over their first latdim columns -- the mean too, Model.py:368-369)
+        x_t = x_start = x_start[:, :L]
         if self.noise_scale != 0:
             sa, sb = self._dev("sqrt_alphas_cumprod", dev), self._dev("sqrt_one_minus_alphas_cumprod", dev)
-            x_t = sa[ts][:, None] * x_start + sb[ts][:, None] * noise                 # q_sample (Model.py:302-305)
-        out = model.forward_layers(x_t, ts, True, keep_mask)
-        mse = self.mean_flat((targetEmbeds - out) ** 2)
+            x_t = sa[ts][:, None] * x_start + sb[ts][:, None] * noise[:, :L]          # q_sample (Model.py:302-305)
+        out = model.forward_layers(x_t, ts, True, None if keep_mask is None else keep_mask[:, :L])
+        mse = self.mean_flat((targetEmbeds[:, :L] - out) ** 2)
+        if wide != L:
+            out = torch.nn.functional.pad(out, (0, wide - L))
         return self._dev("loss_weight", dev, torch.float64)[ts] * mse, out            # (SNR(t-1) - SNR(t), 1 at t = 0)
 
     def mean_flat(self, tensor):  # Model.py:368-369

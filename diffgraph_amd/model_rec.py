@@ -215,18 +215,21 @@ class HGDM(nn.Module):
     def __init__(self, data_handler, args=None, device="cuda"):
         super().__init__()
         self.args = args = args or DEFAULT_ARGS
-        if args.latdim != DG_D:
-            raise NotImplementedError(f"kernels are built for latdim={DG_D}")
+        if not 1 <= args.latdim <= DG_D:
+            raise NotImplementedError(f"the kernels' rows are {DG_D} floats wide: latdim must be in 1..{DG_D} (got {args.latdim})")
         self.n_user, self.n_item = data_handler.userNum, data_handler.itemNum
         bm = data_handler.behavior_mats
         self.behavior_mats = [bm[k] for k in sorted(bm)] if isinstance(bm, dict) else list(bm)
         self.target_adj = data_handler.target_adj
         self.n_hid, self.n_layers = args.latdim, args.gcn_layer
         # one [n_user+n_item, 64] table; user_emb / item_emb are views, so the concatenation
-        # at Model.py:55-56 costs nothing
-        table = torch.empty(self.n_user + self.n_item, self.n_hid, device=device)
-        nn.init.xavier_uniform_(table[: self.n_user])
-        nn.init.xavier_uniform_(table[self.n_user:])
+        # at Model.py:55-56 costs nothing.  With latdim < 64 the columns from latdim on are zero and stay zero: every
+        # kernel on the path sums over a row's columns or treats them alike, the zero columns of the denoisers' outputs
+        # and of the noise (cal_loss_vector) keep their gradient at exactly zero, and Adam leaves a zero with a zero
+        # gradient where it is.
+        table = torch.zeros(self.n_user + self.n_item, DG_D, device=device)
+        nn.init.xavier_uniform_(table[: self.n_user, : self.n_hid])
+        nn.init.xavier_uniform_(table[self.n_user:, : self.n_hid])
         self.embedding_table = nn.Parameter(table)
         self.act = nn.LeakyReLU(0.5, inplace=True)
         self.layers = nn.ModuleList(
@@ -264,7 +267,7 @@ class HGDM(nn.Module):
             n = self.n_user + self.n_item
             self._merged, self._merged_key = False, list(graphs)   # the graphs themselves: an id() can be handed out again
             if all(g.is_symmetric and g.schedule()["lds_split"] == 0 and g.schedule()["dense_splits"] == 0 for g in graphs) \
-                    and len(graphs) * n * self.n_hid * 4 < 2 ** 32:
+                    and len(graphs) * n * DG_D * 4 < 2 ** 32:
                 rows, cols, weights = [], [], []
                 for k, g in enumerate(graphs):
                     rowptr, colidx = g.csr()
@@ -334,12 +337,17 @@ class HGDM(nn.Module):
 
     @property
     def embedding_dict(self):
-        return {"user_emb": self.embedding_table[: self.n_user], "item_emb": self.embedding_table[self.n_user:]}
+        """The reference's two tables, [n_user, latdim] and [n_item, latdim], as views of the one table."""
+        L = self.n_hid
+        return {"user_emb": self.embedding_table[: self.n_user, :L], "item_emb": self.embedding_table[self.n_user:, :L]}
 
     def set_embeddings(self, user_emb: torch.Tensor, item_emb: torch.Tensor) -> None:
+        """Takes the reference's [rows, latdim] tables (or 64-wide ones whose columns from latdim on are zero)."""
+        L = self.n_hid
         with torch.no_grad():
-            self.embedding_table[: self.n_user].copy_(user_emb)
-            self.embedding_table[self.n_user:].copy_(item_emb)
+            self.embedding_table.zero_()
+            self.embedding_table[: self.n_user, :L].copy_(user_emb[:, :L])
+            self.embedding_table[self.n_user:, :L].copy_(item_emb[:, :L])
 
     def propagate(self, e0: torch.Tensor):
         """Returns (ui_embeddings [N,64], all_heter_embeddings [N,64])  (Model.py:61-87)."""
@@ -358,7 +366,7 @@ class HGDM(nn.Module):
         if self._gset is None or not _same_objects(self._gset_graphs, graphs):      # (graphs swapped since: build it anew)
             n = self.n_user + self.n_item
             self._gset, self._gset_graphs = False, list(graphs)
-            if 2 <= len(graphs) <= 4 and len(graphs) * n * self.n_hid * 4 < 2 ** 32 and all(
+            if 2 <= len(graphs) <= 4 and len(graphs) * n * DG_D * 4 < 2 ** 32 and all(
                     g.num_nodes() == n and g.is_symmetric and g.schedule()["lds_split"] == 0
                     and g.schedule()["dense_splits"] == 0 for g in graphs):
                 self._gset = GraphSet(graphs, device=self.embedding_table.device)
@@ -447,8 +455,11 @@ class HGDM(nn.Module):
         return kept[1]
 
     def forward(self):
+        """(target_user, target_item, heter_user, heter_item), each [rows, latdim] (Model.py:53-92)."""
         ui, het = self.propagate(self.embedding_table)
-        nu = self.n_user
+        nu, L = self.n_user, self.n_hid
+        if L != DG_D:
+            return ui[:nu, :L], ui[nu:, :L], het[:nu, :L], het[nu:, :L]
         return ui[:nu], ui[nu:], het[:nu], het[nu:]
 
     def cal_loss(self, ancs, poss, negs, ts_u=None, noise_u=None, ts_i=None, noise_i=None, keep_u=None, keep_i=None):  # Model.py:94-111
@@ -513,8 +524,10 @@ class HGDM(nn.Module):
         return _RecHeadFn.apply(ui, out_u, out_i, rl_u, rl_i, ancs, poss, negs, nu, float(self.args.batch), float(self.args.reg))
 
     def predict(self):  # Model.py:112-118
-        usrEmbeds, itmEmbeds, h_usrEmbeds, h_itemEmbeds = self.forward()
+        ui, het = self.propagate(self.embedding_table)
+        nu, L = self.n_user, self.n_hid
         dp = self.diffusion_process
-        denoised_u, denoised_i = dp.p_sample_many([(self.usr_denoiser, h_usrEmbeds), (self.item_denoiser, h_itemEmbeds)],
+        denoised_u, denoised_i = dp.p_sample_many([(self.usr_denoiser, het[:nu]), (self.item_denoiser, het[nu:])],
                                                   self.args.sampling_steps)
-        return usrEmbeds + denoised_u, itmEmbeds + denoised_i
+        pu, pi = ui[:nu] + denoised_u, ui[nu:] + denoised_i
+        return (pu, pi) if L == DG_D else (pu[:, :L], pi[:, :L])

@@ -156,6 +156,45 @@ def test_training_mode_dropout_losses_and_gradients():
             assert_rows_close(getattr(w, nm).grad, tr["grad_" + pre + nm], rtol=1e-4, what="grad " + pre + nm)
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_narrow_latent_space(mode):
+    """--latdim 32 (params.py:14): the oracle is shape-generic over the one-layer denoiser, so the same restatement must
+    reproduce the reference's run at embeddings [n, 32], in_layers 40->64, out_layers 64->32 (rec_tiny_latdim.npz)."""
+    fx = load("rec_tiny_latdim.npz")
+    _, nu, ni, target, behs = tiny_fixture()
+    tab = O.DiffusionTables(**REC_TABLE)
+
+    def weights(pre):
+        return O.DenoiseWeights(*[T(fx[pre + k]).clone().requires_grad_(True)
+                                  for k in ("emb_w", "emb_b", "in0_w", "in0_b", "out0_w", "out0_b")])
+    ue, ie = T(fx["user_emb"]).clone().requires_grad_(True), T(fx["item_emb"]).clone().requires_grad_(True)
+    wu, wi = weights("usr_"), weights("item_")
+    if mode == "eval":
+        with torch.no_grad():
+            tu, ti, hu, hi = O.rec_forward(target, behs, ue, ie, 2)
+            assert tuple(hu.shape) == (nu, 32)
+            assert_rows_close(O.denoise_forward(wu, hu, T(fx["q_t"])), fx["dn_out_mixed"], what="denoise mixed t")
+            assert_rows_close(O.p_sample(tab, wu, hu, 0), fx["ps_usr_x0"], what="p_sample")
+            loss, out = O.training_losses2(tab, wu, tu, hu, T(fx["tl_batch"]), T(fx["tl_ts"]), T(fx["tl_noise"]))
+            np.testing.assert_allclose(loss.numpy(), fx["tl_loss"], rtol=1e-5)
+            assert_rows_close(out, fx["tl_out"], what="tl out")
+            assert_rows_close(tu + O.p_sample(tab, wu, hu, 0), fx["predict_u"], what="predict")
+    pre = mode + "_"
+    keep = (T(fx[pre + "keep_u"]), T(fx[pre + "keep_i"])) if mode == "train" else (None, None)
+    batch, reg = fx["cl_batch_div"]
+    loss, bpr, regl, diff = O.rec_cal_loss(tab, wu, wi, target, behs, ue, ie, T(fx["cl_ancs"]), T(fx["cl_poss"]), T(fx["cl_negs"]),
+                                           T(fx[pre + "ts_u"]), T(fx[pre + "noise_u"]), T(fx[pre + "ts_i"]), T(fx[pre + "noise_i"]),
+                                           batch, reg, *keep)
+    np.testing.assert_allclose([loss.item(), bpr.item(), regl.item(), diff.item()], fx[pre + "losses"], rtol=1e-6)
+    loss.backward()
+    assert_rows_close(ue.grad, fx[pre + "grad_user"], rtol=1e-4, what="grad user_emb")
+    assert_rows_close(ie.grad, fx[pre + "grad_item"], rtol=1e-4, what="grad item_emb")
+    for who, w in (("usr_", wu), ("item_", wi)):
+        for attr, nm in (("w_emb", "emb_w"), ("b_emb", "emb_b"), ("w_in", "in0_w"), ("b_in", "in0_b"), ("w_out", "out0_w"),
+                         ("b_out", "out0_b")):
+            assert_rows_close(getattr(w, attr).grad, fx[f"{pre}grad_{who}{nm}"], rtol=1e-4, what=f"grad {who}{nm}")
+
+
 def _dblp_graphs():
     import scipy.sparse as sp
     g = load("dblp_graph.npz")

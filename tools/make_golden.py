@@ -135,7 +135,7 @@ def denoiser_state(dn, prefix):
             prefix + "w_out": np64(dn.out_layers[0].weight), prefix + "b_out": np64(dn.out_layers[0].bias)}
 
 
-def build_rec_model(Model, wl, seed):
+def build_rec_model(Model, wl, seed, latdim=64):
     from diffgraph_amd import data as dgdata
     nu, ni = wl.n_user, wl.n_item
     mk = lambda ui: FakeGraph(*dgdata.bipartite_edges(ui[0], ui[1], nu), nu + ni)
@@ -144,8 +144,8 @@ def build_rec_model(Model, wl, seed):
     torch.manual_seed(seed)
     model = Model.HGDM(handler)
     model.eval()  # dropout off: parity runs are deterministic
-    ue = torch.from_numpy(dgdata.xavier_uniform(nu, 64, seed=0))
-    ie = torch.from_numpy(dgdata.xavier_uniform(ni, 64, seed=1))
+    ue = torch.from_numpy(dgdata.xavier_uniform(nu, latdim, seed=0))
+    ie = torch.from_numpy(dgdata.xavier_uniform(ni, latdim, seed=1))
     with torch.no_grad():
         model.embedding_dict["user_emb"].copy_(ue)
         model.embedding_dict["item_emb"].copy_(ie)
@@ -321,15 +321,26 @@ def gen_rec_dims():
     """The tiny Rec model with a second denoiser configuration, --dims '[128, 32]' --d_emb_size 10 (in_layers
     74->32->128, out_layers 128->32->64; params.py:32-33, Model.py:177-191,226-232): Denoise.forward, training_losses2,
     p_sample, predict, and cal_loss + backward in eval and in training mode, with the draws torch made recorded."""
+    _gen_rec_variant("rec_tiny_dims.npz", "[128, 32]", 10, 64, [(32, 74), (128, 32)], [(32, 128), (64, 32)])
+
+
+def gen_rec_latdim():
+    """... and with a narrower latent space, --latdim 32 (params.py:14; embeddings [n, 32], in_layers 40->64,
+    out_layers 64->32): the same calls; the embeddings are the first 32 columns' worth of a fresh xavier draw."""
+    _gen_rec_variant("rec_tiny_latdim.npz", "[64]", 8, 32, [(64, 40)], [(32, 64)])
+
+
+def _gen_rec_variant(out_name, dims, d_emb_size, latdim, want_in, want_out):
     Model = import_reference("DiffGraph-Rec")
     from diffgraph_amd import data as dgdata
-    Model.args.dims, Model.args.d_emb_size = "[128, 32]", 10
+    Model.args.dims, Model.args.d_emb_size, Model.args.latdim = dims, d_emb_size, latdim
     wl = dgdata.rec_workload("tiny")
-    model, handler = build_rec_model(Model, wl, seed=7)
+    model, handler = build_rec_model(Model, wl, seed=7, latdim=latdim)
     nu, ni = wl.n_user, wl.n_item
-    assert [tuple(l.weight.shape) for l in model.usr_denoiser.in_layers] == [(32, 74), (128, 32)]
-    assert [tuple(l.weight.shape) for l in model.usr_denoiser.out_layers] == [(32, 128), (64, 32)]
-    fx = {"dims": np.array([128, 32]), "d_emb_size": np.array([10])}
+    assert [tuple(l.weight.shape) for l in model.usr_denoiser.in_layers] == want_in
+    assert [tuple(l.weight.shape) for l in model.usr_denoiser.out_layers] == want_out
+    fx = {"dims": np.array(eval(dims)), "d_emb_size": np.array([d_emb_size]), "latdim": np.array([latdim])}
+    fx["user_emb"], fx["item_emb"] = np64(model.embedding_dict["user_emb"]), np64(model.embedding_dict["item_emb"])
     fx.update(denoiser_layers(model.usr_denoiser, "usr_"))
     fx.update(denoiser_layers(model.item_denoiser, "item_"))
     dp = model.diffusion_process
@@ -376,8 +387,8 @@ def gen_rec_dims():
             for nm, q in grads.items():
                 fx[pre + "grad_" + who + nm] = np64(q)
     fx["cl_batch_div"] = np.array([Model.args.batch, Model.args.reg], dtype=np.float64)
-    np.savez_compressed(os.path.join(OUT, "rec_tiny_dims.npz"), **fx)
-    print("rec_tiny_dims.npz:", len(fx), "arrays")
+    np.savez_compressed(os.path.join(OUT, out_name), **fx)
+    print(out_name + ":", len(fx), "arrays")
 
 
 # --------------------------------------------------------------------------------------
@@ -623,9 +634,9 @@ def gen_metapath():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "nc", "nc_train", "eval", "metapath"]
+    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "nc", "nc_train", "eval", "metapath"]
     if len(which) == 1:
-        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "nc": gen_nc, "nc_train": gen_nc_train, "eval": gen_eval,
+        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "nc": gen_nc, "nc_train": gen_nc_train, "eval": gen_eval,
          "metapath": gen_metapath}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
