@@ -122,3 +122,57 @@ def test_general_denoiser_coach_epochs(use_graph):
     assert not c.model.usr_denoiser.fused
     assert len(lines) == 4 and all("nan" not in ln.lower() for ln in lines), lines
     assert 0.0 <= res["Recall"] <= 1.0 and len(c.metrics["TestRecall"]) == 2
+
+
+def _nc_model_and_fixture():
+    from tests.test_oracle_golden import _dblp_graphs
+    fx = load("nc_dblp_dims.npz")
+    NA, apa, apcpa, aptpa, features = _dblp_graphs()
+    adjs = [dg.CSRGraph.from_scipy(apa) for _ in range(3)]
+    args = SimpleNamespace(**{**vars(dg.nc.DEFAULT_ARGS), "dims": str([int(v) for v in fx["dims"]]), "d_emb_size": int(fx["d_emb_size"][0])})
+    model = dg.nc.HGDM(features.shape[1], args).train()     # (the reference's NC program never leaves training mode)
+    assert not model.user_denoise_model.fused
+    with torch.no_grad():
+        for nm, prm in model.named_parameters():
+            prm.copy_(dev(fx["param_" + nm.replace(".", "_")]))
+    return model, fx, NA, adjs, features
+
+
+def test_nc_general_denoiser_golden():
+    """DiffGraph_NC with --dims '[128, 32]' --d_emb_size 10 against the reference's own run on DBLP (as-coded graphs,
+    tests/golden/nc_dblp_dims.npz): get_allembeds (the reverse loop layer by layer), one training step's two losses and
+    the gradients of all fourteen parameter tensors, with the timesteps, noise and dropout mask torch drew for it."""
+    model, fx, NA, adjs, features = _nc_model_and_fixture()
+    with torch.no_grad():
+        emb, scores = model.get_allembeds(adjs, dev(features))
+    assert_rows_close(emb, fx["all_embeddings"], rtol=1e-5, what="all_embeddings")
+    assert_rows_close(scores, fx["scores"], rtol=1e-5, what="scores")
+    onehot = torch.zeros(NA, 4)
+    onehot[torch.arange(NA), torch.from_numpy(load("dblp_graph.npz")["labels"]).long()] = 1.0
+    nll, diff = model.cal_loss(dev(fx["cl_ancs"]), dev(onehot), adjs, dev(features), dev(fx["ts"]), dev(fx["noise"]), dev(fx["keep"]))
+    np.testing.assert_allclose([float(nll.detach()), float(diff.detach())], fx["losses"], rtol=1e-5)
+    (nll + diff).backward()
+    checked = 0
+    for nm, prm in model.named_parameters():
+        key = "grad_" + nm.replace(".", "_")
+        if key in fx.files:
+            assert prm.grad is not None, nm
+            assert_close_to_max(prm.grad, fx[key], GRAD_TOL, "grad " + nm)
+            checked += 1
+    assert checked == 14
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_nc_general_denoiser_coach_epochs(use_graph):
+    """NCCoach over two epochs with the general denoiser, eagerly and with the step recorded as a HIP graph."""
+    import copy
+    from diffgraph_amd.train_nc import NCCoach
+    from tests.test_gpu_train import _nc_handler
+    args = copy.copy(dg.nc.DEFAULT_ARGS)
+    args.dims, args.d_emb_size, args.batch = "[128, 32]", 10, 8
+    c = NCCoach(_nc_handler(), args, device=DEV, use_graph=use_graph, seed=3)
+    lines = []
+    res = c.run(epochs=2, log=lines.append)
+    assert not c.model.user_denoise_model.fused
+    assert len(lines) == 2 and all("nan" not in ln.lower() for ln in lines), lines
+    assert 0.0 <= res["macro"] <= 1.0

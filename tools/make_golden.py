@@ -533,6 +533,55 @@ def gen_nc_train():
     print("nc_dblp_train.npz:", len(fx), "arrays; keep fraction", fx["keep"].mean())
 
 
+def gen_nc_dims():
+    """The NC model with a second denoiser configuration, --dims '[128, 32]' --d_emb_size 10 (DiffGraph_NC/params.py;
+    in_layers 74->32->128, out_layers 128->32->64), on the as-coded graphs (3 x APA): one training step in training mode
+    (losses and every parameter's gradient, the draws recorded) and get_allembeds (the reverse loop, dropout off)."""
+    Model = import_reference("DiffGraph_NC")
+    import scipy.sparse as sp
+    Model.args.dims, Model.args.d_emb_size = "[128, 32]", 10
+    feats, edges, labels = load_dblp()
+    NA = feats.shape[0]
+    ap = edges["ap"]
+    NP = max(ap[:, 1].max(), edges["pa"][:, 0].max()) + 1
+    rowsum = np.array(feats.sum(1)).flatten()
+    r_inv = np.power(rowsum, -1).flatten()
+    r_inv[np.isinf(r_inv)] = 0.0
+    features = torch.FloatTensor(np.asarray(sp.diags(r_inv).dot(feats).todense()))
+    A_P = sp.coo_matrix((np.ones(len(ap)), (ap[:, 0], ap[:, 1])), shape=(NA, NP)).tocsr()
+    apa = ((A_P @ A_P.T) != 0).astype(np.float32).tocoo()
+    adjs = [FakeGraph(apa.row, apa.col, NA) for _ in range(3)]
+    torch.manual_seed(29)
+    model = Model.HGDM(features.shape[1])
+    dn = model.user_denoise_model
+    assert [tuple(l.weight.shape) for l in dn.in_layers] == [(32, 74), (128, 32)]
+    assert [tuple(l.weight.shape) for l in dn.out_layers] == [(32, 128), (64, 32)]
+    model.train()
+    fx = {"dims": np.array([128, 32]), "d_emb_size": np.array([10])}
+    for nm, q in model.named_parameters():
+        fx["param_" + nm.replace(".", "_")] = np64(q)
+    onehot = torch.zeros(NA, 4)
+    onehot[torch.arange(NA), torch.from_numpy(labels).long()] = 1.0
+    ancs = torch.from_numpy(np.load(os.path.join(OUT, "nc_dblp.npz"))["cl_ancs"])
+    fx["cl_ancs"] = np64(ancs)
+    with torch.no_grad():
+        emb, scores = model.get_allembeds(adjs, features)
+        fx["all_embeddings"], fx["scores"] = np64(emb), np64(scores)
+    model.zero_grad()
+    with Recorder() as rec:
+        torch.manual_seed(47)
+        nll, diff = model.cal_loss(ancs, onehot, adjs, features)
+    (nll + diff).backward()
+    fx.update({"ts": np64(rec.randint[0]), "noise": np64(rec.randn[0]), "keep": np64(rec.dropout[0]).astype(np.uint8),
+               "losses": np.array([nll.item(), diff.item()], dtype=np.float64)})
+    assert len(rec.dropout) == 1 and fx["keep"].shape == (NA, 64)
+    for nm, q in model.named_parameters():
+        if q.grad is not None:
+            fx["grad_" + nm.replace(".", "_")] = np64(q.grad)
+    np.savez_compressed(os.path.join(OUT, "nc_dblp_dims.npz"), **fx)
+    print("nc_dblp_dims.npz:", len(fx), "arrays; keep fraction", fx["keep"].mean())
+
+
 # --------------------------------------------------------------------------------------
 # Rec all-rank evaluation (Coach.testEpoch / calcRes, AllRankTestData)
 # --------------------------------------------------------------------------------------
@@ -634,9 +683,9 @@ def gen_metapath():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "nc", "nc_train", "eval", "metapath"]
+    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "nc", "nc_train", "nc_dims", "eval", "metapath"]
     if len(which) == 1:
-        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "nc": gen_nc, "nc_train": gen_nc_train, "eval": gen_eval,
+        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "nc": gen_nc, "nc_train": gen_nc_train, "nc_dims": gen_nc_dims, "eval": gen_eval,
          "metapath": gen_metapath}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
