@@ -12,15 +12,27 @@
 // The user's sorted training row is walked in step with the item tiles, so masking costs a register
 // compare per tile; a score is compared with the worst entry of the lane's list, and of the list
 // the other half-wavefront keeps for the same user, before anything else happens to it.
+//
+// The scores themselves come off the bf16 matrix instruction at 6/16 of the exact-fp32 instruction's cycles: an fp32
+// value is the sum of three bf16 numbers exactly (its 24 significand bits in three runs of eight), products of bf16
+// numbers are exact in the fp32 accumulator, and of the nine cross products the six that matter leave out less than
+// one fp32 rounding of the score (as in the reverse loop, diffusion.hip).  DG_EVAL_FP32=1 keeps the fp32 instruction.
 #include "dg_internal.h"
+
+#include <stdlib.h>
 
 #include <math.h>
 
 #include <algorithm>
 #include <climits>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -30,6 +42,25 @@ constexpr int kTile = 32;                // items per tile
 constexpr int kPitch = 68;               // floats per staged item row (64 + 4: conflict-free ds_read_b128)
 constexpr float kMasked = -1e8f;         // main.py:157
 constexpr int kBuf = 16;                 // parked candidates per lane between two list merges (two half tiles)
+constexpr int kPlanePitch = 9;           // u32x4 per staged item row of one bf16 plane (8 + 1: conflict-free ds_read_b128)
+constexpr int kPlaneTile = kTile * kPlanePitch;
+constexpr int kMaxLocalTiles = 65536 / kTile;   // the bf16 form parks an item as a 16-bit offset into its workgroup's range
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+// eight fp32 -> three bf16 planes with hi + mid + lo == x up to the bits below the 24th (the remainders are exact)
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 &hi, u32x4 &mid, u32x4 &lo) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a = x[2 * k], b = x[2 * k + 1];
+    const unsigned h = pack_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    const unsigned m = pack_bf16(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    hi[k] = h; mid[k] = m; lo[k] = pack_bf16(sa, sb);
+  }
+}
 
 struct topk_args {
   const float *usr_emb, *item_emb;
@@ -52,11 +83,18 @@ __device__ __forceinline__ int lower_bound(const int32_t *__restrict__ col, int 
 // KPAD: list slots per lane (k rounded up to a multiple of 4).  The list lives in registers, sorted by
 // falling score; slots [0, KPAD - k) hold +inf and never move, so the lane's worst entry is always
 // the last slot.  A new score enters through a compare-and-shift over all slots (no indexed access).
-template <int KPAD>
-__global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
-  __shared__ float tile[2 * kTile * kPitch];
+// B3: the scores on the bf16 instruction.  The staging threads cut the item rows into three bf16 planes once per
+// tile (a thread's eight floats are exactly one lane's operand of one 16-feature chunk: features 32 h + 8 c .. + 7 on
+// lane half h, for the items as for the users -- the matrix instruction only needs both operands to agree on which
+// k is which), and parked items are 16-bit offsets into the workgroup's item range, so that three workgroups still
+// share a CU's LDS.
+template <int KPAD, bool B3>
+__global__ __launch_bounds__(256, 3) void score_topk_kernel(const topk_args a) {
+  __shared__ u32x4 tile_raw[B3 ? 2 * 3 * kPlaneTile : 2 * kTile * kPitch / 4];
   __shared__ float bs[kBuf * 256];  // parked scores [slot][thread] ...
-  __shared__ int bi[kBuf * 256];    // ... and their item ids
+  typedef typename std::conditional<B3, uint16_t, int>::type park_t;
+  __shared__ park_t bi[kBuf * 256];  // ... and their item ids (B3: offsets from the first item of the workgroup's range)
+  float *tile = reinterpret_cast<float *>(tile_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
   const int k = a.k;
   const int t_idx = blockIdx.x * kUsersPerBlock + wave * 32 + j;
@@ -70,6 +108,14 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (valid) v = *reinterpret_cast<const f32x4 *>(a.usr_emb + user * DG_D + 32 * h + 4 * c);
     ub[4 * c] = v.x; ub[4 * c + 1] = v.y; ub[4 * c + 2] = v.z; ub[4 * c + 3] = v.w;
+  }
+  u32x4 uh[4], um[4], ul[4];   // B3: the same features as bf16 planes, chunk c = features 32 h + 8 c .. + 7
+  if (B3) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x[8] = {ub[8 * c], ub[8 * c + 1], ub[8 * c + 2], ub[8 * c + 3], ub[8 * c + 4], ub[8 * c + 5], ub[8 * c + 6], ub[8 * c + 7]};
+      split8(x, uh[c], um[c], ul[c]);
+    }
   }
   float ls[KPAD];
   int li[KPAD];
@@ -88,12 +134,14 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
   float bound = valid ? -INFINITY : INFINITY;
   const int mid_slot = KPAD - k + (k + 1) / 2 - 1;
   int nb = 0;
+  const int tile0 = blockIdx.y * a.tiles_per_split;
+  const int id0 = B3 ? tile0 * kTile : 0;
   auto compact = [&]() {
 #pragma nounroll
     for (int b = 0; b < kBuf; ++b) {
       const bool have = b < nb;
       const float s = have ? bs[b * 256 + tid] : -INFINITY;
-      const int id = have ? bi[b * 256 + tid] : -1;
+      const int id = have ? id0 + (int)bi[b * 256 + tid] : -1;
       if (!__any(have)) break;
       if (s > ls[KPAD - 1]) {
         // slot p takes its upper neighbour when s beats that one too, s when it beats only slot p's entry
@@ -117,7 +165,6 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
     bound = valid ? fmaxf(tau, other) : INFINITY;
   };
 
-  const int tile0 = blockIdx.y * a.tiles_per_split;
   const int n_tiles_all = (a.n_item + kTile - 1) / kTile;
   const int tile1 = min(tile0 + a.tiles_per_split, n_tiles_all);
   // the user's training items, walked in step with the item tiles (both ascend)
@@ -137,6 +184,14 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
     }
   };
   auto stage = [&](int buf, f32x4 v0, f32x4 v1) {
+    if (B3) {
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      u32x4 hi, mid, lo;
+      split8(x, hi, mid, lo);
+      u32x4 *dst = tile_raw + buf * 3 * kPlaneTile + (tid >> 3) * kPlanePitch + (tid & 7);
+      dst[0] = hi; dst[kPlaneTile] = mid; dst[2 * kPlaneTile] = lo;
+      return;
+    }
     float *dst = tile + (buf * kTile + (tid >> 3)) * kPitch + 8 * (tid & 7);
     *reinterpret_cast<f32x4 *>(dst) = v0;
     *reinterpret_cast<f32x4 *>(dst + 4) = v1;
@@ -152,13 +207,31 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (B3) {
+      const u32x4 *ap = tile_raw + buf * 3 * kPlaneTile + j * kPlanePitch + 4 * h;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + 4 * c);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, ub[4 * c], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, ub[4 * c + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, ub[4 * c + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, ub[4 * c + 3], acc, 0, 0, 0);
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, ap[c]), am = __builtin_bit_cast(bf16x8, ap[kPlaneTile + c]),
+                     al = __builtin_bit_cast(bf16x8, ap[2 * kPlaneTile + c]);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, uh[c]), bm = __builtin_bit_cast(bf16x8, um[c]),
+                     bl = __builtin_bit_cast(bf16x8, ul[c]);
+        // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + 4 * c);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, ub[4 * c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, ub[4 * c + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, ub[4 * c + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, ub[4 * c + 3], acc, 0, 0, 0);
+      }
     }
     // acc[r]: user j, item t*32 + 8 (r >> 2) + 4 h + (r & 3)
     const int item0 = t * kTile;
@@ -190,7 +263,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const topk_args a) {
         if (__any(cand)) {
           if (cand) {
             bs[nb * 256 + tid] = acc[rr];
-            bi[nb * 256 + tid] = item0 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+            bi[nb * 256 + tid] = (park_t)(item0 - id0 + 8 * (rr >> 2) + 4 * h + (rr & 3));
             ++nb;
           }
         }
@@ -315,10 +388,15 @@ extern "C" int dg_eval_topk(const float *usr_emb, const float *item_emb, int32_t
   a.cand_idx = (int32_t *)(a.cand_score + (size_t)n_test * 2 * n_split * k);
   a.n_test = n_test; a.n_item = n_item; a.k = k; a.n_split = n_split;
   a.tiles_per_split = (n_tiles + n_split - 1) / n_split;
-  static void (*const kerns[8])(const topk_args) = {score_topk_kernel<4>,  score_topk_kernel<8>,  score_topk_kernel<12>,
-                                                     score_topk_kernel<16>, score_topk_kernel<20>, score_topk_kernel<24>,
-                                                     score_topk_kernel<28>, score_topk_kernel<32>};
-  void (*kern)(const topk_args) = kerns[(k + 3) / 4 - 1];  // list slots: k rounded up to a multiple of 4
+  static void (*const kerns[2][8])(const topk_args) = {
+      {score_topk_kernel<4, false>, score_topk_kernel<8, false>, score_topk_kernel<12, false>, score_topk_kernel<16, false>,
+       score_topk_kernel<20, false>, score_topk_kernel<24, false>, score_topk_kernel<28, false>, score_topk_kernel<32, false>},
+      {score_topk_kernel<4, true>, score_topk_kernel<8, true>, score_topk_kernel<12, true>, score_topk_kernel<16, true>,
+       score_topk_kernel<20, true>, nullptr, nullptr, nullptr}};
+  const char *fp32_env = getenv("DG_EVAL_FP32");   // (read at every call: a test switches it)
+  // (lists of more than 20 entries leave the bf16 form short of registers at three workgroups per CU)
+  const bool b3 = k <= 20 && a.tiles_per_split <= kMaxLocalTiles && !(fp32_env && atoi(fp32_env) > 0);
+  void (*kern)(const topk_args) = kerns[b3 ? 1 : 0][(k + 3) / 4 - 1];  // list slots: k rounded up to a multiple of 4
   hipLaunchKernelGGL(kern, dim3(tiles, n_split), dim3(256), 0, (hipStream_t)stream, a);
   const int n_cand = 2 * n_split * k;
   auto merge = n_cand <= 128 ? merge_topk_kernel<2> : n_cand <= 256 ? merge_topk_kernel<4> : merge_topk_kernel<8>;  // <= 512

@@ -32,6 +32,33 @@ def check_top_lists(got_idx, got_val, want_idx, scores, what):
                                err_msg=what)
 
 
+def test_scores_on_split_bf16_match_the_fp32_matrix_instruction(monkeypatch):
+    """The scoring kernel's two forms -- the bf16 matrix instruction over fp32 values cut into three bf16 numbers (the
+    default up to k = 20) and the exact-fp32 instruction (DG_EVAL_FP32=1) -- against the fp64 scores and each other:
+    the same lists except at ties within fp32 rounding, values within two fp32 roundings of each other."""
+    nu, ni, k = 700, 5003, 20
+    gen = torch.Generator().manual_seed(77)
+    usr, itm = torch.randn(nu, 64, generator=gen), torch.randn(ni, 64, generator=gen)
+    trn_u, trn_i = dgdata.synth_interactions(nu, ni, 40000, 3)
+    rng = np.random.default_rng(6)
+    data = ev.AllRankTestData(coo(rng.integers(0, nu, nu).astype(np.int32), rng.integers(0, ni, nu).astype(np.int32), nu, ni),
+                              coo(trn_u, trn_i, nu, ni))
+    users = data.test_users_dev
+    mask = np.zeros((nu, ni), np.float32)
+    mask[trn_u, trn_i] = 1.0
+    m = T(mask[data.test_users])
+    scores = (torch.mm(usr[T(data.test_users).long()].double(), itm.double().t()) * (1 - m) - m * 1e8).numpy()
+    _, want = torch.topk(T(scores), k)
+    got = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("DG_EVAL_FP32", form)
+        vals, top = ev.all_rank_topk(usr.to(DEV), itm.to(DEV), users, data, k)
+        got[form] = (top.cpu().numpy(), vals.cpu().numpy())
+        check_top_lists(got[form][0], got[form][1], want.numpy(), scores, f"DG_EVAL_FP32={form}")
+    np.testing.assert_allclose(np.sort(got["0"][1], axis=1), np.sort(got["1"][1], axis=1), rtol=0, atol=2e-6 * np.abs(scores[scores > -1e7]).max())
+    assert (got["0"][0] != got["1"][0]).mean() < 1e-3
+
+
 def test_eval_golden_reference_test_epoch():
     """The reference's own testEpoch run (tools/make_golden.py gen_eval): same test-user order, top-20
     lists, per-user Recall/NDCG bit for bit and the epoch metrics."""
