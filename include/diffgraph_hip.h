@@ -621,6 +621,10 @@ int dg_adam_multi(float *const *params_host, const float *const *grads_host, flo
  * rows.  top_idx / top_score: DEVICE [n_test][k], by falling score; equal scores by rising item id
  * (torch.topk leaves that order open); -1 where a user has fewer than k items.  k <= 32.
  * workspace: DEVICE scratch of dg_eval_topk_workspace() bytes.
+ * The scores are fp32 dot products; for k <= 20 they are formed on the bf16 matrix instruction from the fp32
+ * values cut into three bf16 numbers each (six products per term: what is left out is below one fp32 rounding of
+ * the score), with DG_EVAL_FP32=1 in the environment on the exact-fp32 instruction -- the two differ the way two
+ * fp32 summation orders differ.
  * ---------------------------------------------------------------------------------- */
 size_t dg_eval_topk_workspace(int32_t n_test, int32_t n_item, int32_t k);
 int dg_eval_topk(const float *usr_emb, const float *item_emb, int32_t n_user, int32_t n_item,
