@@ -151,8 +151,11 @@ class HGDM(nn.Module):
     def __init__(self, f_dim, args=None, device="cuda"):
         super().__init__()
         self.args = args = args or DEFAULT_ARGS
-        if args.latdim != DG_D:
-            raise NotImplementedError(f"kernels are built for latdim={DG_D}")
+        if not 1 <= args.latdim <= DG_D:
+            raise NotImplementedError(f"the kernels' rows are {DG_D} floats wide: latdim must be in 1..{DG_D} (got {args.latdim})")
+        # latdim < 64: the tables stay 64 wide with zeros from column latdim on (transform_layer's output and the
+        # classification weights are padded, under autograd: the zero columns neither change a sum nor get a gradient)
+        self.n_hid = args.latdim
         if args.gcn_layer != args.uugcn_layer:
             raise NotImplementedError("fused forward assumes gcn_layer == uugcn_layer (the reference defaults)")
         out_dims = eval(args.dims) + [args.latdim]
@@ -210,9 +213,19 @@ class HGDM(nn.Module):
                 hook("end", l, tasks)
         return sums, saved, norms
 
-    def forward(self, he_adjs, feature_list, is_training=True):
+    def _forward_wide(self, he_adjs, feature_list):
+        """forward() on the kernels' 64-wide rows (zeros from column latdim on)."""
         embed = _LinearFn.apply(feature_list, self.transform_layer.weight, self.transform_layer.bias)
+        if self.n_hid != DG_D:
+            embed = torch.nn.functional.pad(embed, (0, DG_D - self.n_hid))
         target, s1, s2 = self.propagate(he_adjs, embed)
+        return s1, s2, target
+
+    def forward(self, he_adjs, feature_list, is_training=True):
+        s1, s2, target = self._forward_wide(he_adjs, feature_list)
+        if self.n_hid != DG_D:
+            L = self.n_hid
+            return s1[:, :L], s2[:, :L], target[:, :L]
         return s1, s2, target
 
     def cal_loss(self, ancs, label, he_adjs, initial_feature, ts=None, noise=None, keep_mask=None,
@@ -220,7 +233,7 @@ class HGDM(nn.Module):
         """`ts` / `noise` / `keep_mask`: the draws of training_losses2 handed in instead of drawn (`drop_seed`, int64[1]
         on the device: the key the kernels draw the dropout mask from when no mask is given); `validate=False` skips
         the range check of caller-supplied timesteps (a host synchronisation a recorded step cannot have)."""
-        s1, s2, target_embedding = self.forward(he_adjs, initial_feature)
+        s1, s2, target_embedding = self._forward_wide(he_adjs, initial_feature)
         source_embeddings = s1 + s2
         # training_losses2 before its [batch] gather: the head below gathers the batch rows of everything at once
         row_loss, diff_embeddings = self.diffusion_model.training_losses_rows(
@@ -230,16 +243,22 @@ class HGDM(nn.Module):
             label = torch.argmax(label[ancs], dim=-1)        # (any other label table: the batch's labels by torch)
         # all_embeddings = target + diffused, log_softmax(dense(.))[ancs], nll_loss and diff_loss[ancs].mean() in one op:
         # only the batch rows' scores are ever used
-        return _LossHeadFn.apply(target_embedding, diff_embeddings, row_loss, self.dense.weight, self.dense.bias, ancs, label)
+        return _LossHeadFn.apply(target_embedding, diff_embeddings, row_loss, self._dense_weight(), self.dense.bias, ancs, label)
+
+    def _dense_weight(self) -> torch.Tensor:
+        """dense.weight [classes, latdim] as the kernels take it: [classes, 64], zeros behind the columns."""
+        w = self.dense.weight
+        return w if self.n_hid == DG_D else torch.nn.functional.pad(w, (0, DG_D - self.n_hid))
 
     def get_embeds(self, ancs, label, he_adjs, initial_feature):  # Model.py:90-99
         all_embeddings, _ = self.get_allembeds(he_adjs, initial_feature)
         return all_embeddings[ancs]
 
     def get_allembeds(self, he_adjs, initial_feature):  # Model.py:100-108
-        s1, s2, target_embedding = self.forward(he_adjs, initial_feature)
+        s1, s2, target_embedding = self._forward_wide(he_adjs, initial_feature)
         source_embeddings = s1 + s2
         diff_embeddings = self.diffusion_model.p_sample(self.user_denoise_model, source_embeddings, self.args.sampling_steps)
         all_embeddings = target_embedding + diff_embeddings
-        return all_embeddings, ops.nc_logits(all_embeddings.contiguous(), self.dense.weight.detach().contiguous(),
-                                             self.dense.bias.detach().contiguous())
+        scores = ops.nc_logits(all_embeddings.contiguous(), self._dense_weight().detach().contiguous(),
+                               self.dense.bias.detach().contiguous())
+        return (all_embeddings if self.n_hid == DG_D else all_embeddings[:, : self.n_hid]), scores

@@ -124,12 +124,13 @@ def test_general_denoiser_coach_epochs(use_graph):
     assert 0.0 <= res["Recall"] <= 1.0 and len(c.metrics["TestRecall"]) == 2
 
 
-def _nc_model_and_fixture():
+def _nc_model_and_fixture(name):
     from tests.test_oracle_golden import _dblp_graphs
-    fx = load("nc_dblp_dims.npz")
+    fx = load(name)
     NA, apa, apcpa, aptpa, features = _dblp_graphs()
     adjs = [dg.CSRGraph.from_scipy(apa) for _ in range(3)]
-    args = SimpleNamespace(**{**vars(dg.nc.DEFAULT_ARGS), "dims": str([int(v) for v in fx["dims"]]), "d_emb_size": int(fx["d_emb_size"][0])})
+    args = SimpleNamespace(**{**vars(dg.nc.DEFAULT_ARGS), "dims": str([int(v) for v in fx["dims"]]), "d_emb_size": int(fx["d_emb_size"][0]),
+                              "latdim": int(fx["latdim"][0]) if "latdim" in fx.files else 64})
     model = dg.nc.HGDM(features.shape[1], args).train()     # (the reference's NC program never leaves training mode)
     assert not model.user_denoise_model.fused
     with torch.no_grad():
@@ -138,13 +139,17 @@ def _nc_model_and_fixture():
     return model, fx, NA, adjs, features
 
 
-def test_nc_general_denoiser_golden():
-    """DiffGraph_NC with --dims '[128, 32]' --d_emb_size 10 against the reference's own run on DBLP (as-coded graphs,
-    tests/golden/nc_dblp_dims.npz): get_allembeds (the reverse loop layer by layer), one training step's two losses and
-    the gradients of all fourteen parameter tensors, with the timesteps, noise and dropout mask torch drew for it."""
-    model, fx, NA, adjs, features = _nc_model_and_fixture()
+@pytest.mark.parametrize("name, n_tensors", [("nc_dblp_dims.npz", 14), ("nc_dblp_latdim.npz", 10)])
+def test_nc_general_denoiser_golden(name, n_tensors):
+    """DiffGraph_NC with --dims '[128, 32]' --d_emb_size 10, and with --latdim 32 (64-wide zero-padded tables, as in
+    the recommendation model), against the reference's own runs on DBLP (as-coded graphs, tests/golden/nc_dblp_dims.npz /
+    nc_dblp_latdim.npz): get_allembeds (the reverse loop layer by layer), one training step's two losses and the
+    gradients of every parameter tensor, with the timesteps, noise and dropout mask torch drew for it."""
+    model, fx, NA, adjs, features = _nc_model_and_fixture(name)
     with torch.no_grad():
         emb, scores = model.get_allembeds(adjs, dev(features))
+        s1, s2, tgt = model.forward(adjs, dev(features))
+    assert tuple(emb.shape) == tuple(fx["all_embeddings"].shape) == tuple(tgt.shape)
     assert_rows_close(emb, fx["all_embeddings"], rtol=1e-5, what="all_embeddings")
     assert_rows_close(scores, fx["scores"], rtol=1e-5, what="scores")
     onehot = torch.zeros(NA, 4)
@@ -159,17 +164,19 @@ def test_nc_general_denoiser_golden():
             assert prm.grad is not None, nm
             assert_close_to_max(prm.grad, fx[key], GRAD_TOL, "grad " + nm)
             checked += 1
-    assert checked == 14
+    assert checked == n_tensors
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_nc_general_denoiser_coach_epochs(use_graph):
-    """NCCoach over two epochs with the general denoiser, eagerly and with the step recorded as a HIP graph."""
+@pytest.mark.parametrize("dims, d_emb_size, latdim", [("[128, 32]", 10, 64), ("[64]", 8, 32)])
+def test_nc_general_denoiser_coach_epochs(use_graph, dims, d_emb_size, latdim):
+    """NCCoach over two epochs with the general denoiser (another --dims / --d_emb_size; --latdim 32), eagerly and with
+    the step recorded as a HIP graph."""
     import copy
     from diffgraph_amd.train_nc import NCCoach
     from tests.test_gpu_train import _nc_handler
     args = copy.copy(dg.nc.DEFAULT_ARGS)
-    args.dims, args.d_emb_size, args.batch = "[128, 32]", 10, 8
+    args.dims, args.d_emb_size, args.latdim, args.batch = dims, d_emb_size, latdim, 8
     c = NCCoach(_nc_handler(), args, device=DEV, use_graph=use_graph, seed=3)
     lines = []
     res = c.run(epochs=2, log=lines.append)

@@ -537,9 +537,18 @@ def gen_nc_dims():
     """The NC model with a second denoiser configuration, --dims '[128, 32]' --d_emb_size 10 (DiffGraph_NC/params.py;
     in_layers 74->32->128, out_layers 128->32->64), on the as-coded graphs (3 x APA): one training step in training mode
     (losses and every parameter's gradient, the draws recorded) and get_allembeds (the reverse loop, dropout off)."""
+    _gen_nc_variant("nc_dblp_dims.npz", "[128, 32]", 10, 64, [(32, 74), (128, 32)], [(32, 128), (64, 32)])
+
+
+def gen_nc_latdim():
+    """... and with --latdim 32 (transform_layer 334->32, in_layers 40->64, out_layers 64->32, dense 32->4)."""
+    _gen_nc_variant("nc_dblp_latdim.npz", "[64]", 8, 32, [(64, 40)], [(32, 64)])
+
+
+def _gen_nc_variant(out_name, dims, d_emb_size, latdim, want_in, want_out):
     Model = import_reference("DiffGraph_NC")
     import scipy.sparse as sp
-    Model.args.dims, Model.args.d_emb_size = "[128, 32]", 10
+    Model.args.dims, Model.args.d_emb_size, Model.args.latdim = dims, d_emb_size, latdim
     feats, edges, labels = load_dblp()
     NA = feats.shape[0]
     ap = edges["ap"]
@@ -554,10 +563,10 @@ def gen_nc_dims():
     torch.manual_seed(29)
     model = Model.HGDM(features.shape[1])
     dn = model.user_denoise_model
-    assert [tuple(l.weight.shape) for l in dn.in_layers] == [(32, 74), (128, 32)]
-    assert [tuple(l.weight.shape) for l in dn.out_layers] == [(32, 128), (64, 32)]
+    assert [tuple(l.weight.shape) for l in dn.in_layers] == want_in
+    assert [tuple(l.weight.shape) for l in dn.out_layers] == want_out
     model.train()
-    fx = {"dims": np.array([128, 32]), "d_emb_size": np.array([10])}
+    fx = {"dims": np.array(eval(dims)), "d_emb_size": np.array([d_emb_size]), "latdim": np.array([latdim])}
     for nm, q in model.named_parameters():
         fx["param_" + nm.replace(".", "_")] = np64(q)
     onehot = torch.zeros(NA, 4)
@@ -574,12 +583,12 @@ def gen_nc_dims():
     (nll + diff).backward()
     fx.update({"ts": np64(rec.randint[0]), "noise": np64(rec.randn[0]), "keep": np64(rec.dropout[0]).astype(np.uint8),
                "losses": np.array([nll.item(), diff.item()], dtype=np.float64)})
-    assert len(rec.dropout) == 1 and fx["keep"].shape == (NA, 64)
+    assert len(rec.dropout) == 1 and fx["keep"].shape == (NA, latdim)
     for nm, q in model.named_parameters():
         if q.grad is not None:
             fx["grad_" + nm.replace(".", "_")] = np64(q.grad)
-    np.savez_compressed(os.path.join(OUT, "nc_dblp_dims.npz"), **fx)
-    print("nc_dblp_dims.npz:", len(fx), "arrays; keep fraction", fx["keep"].mean())
+    np.savez_compressed(os.path.join(OUT, out_name), **fx)
+    print(out_name + ":", len(fx), "arrays; keep fraction", fx["keep"].mean())
 
 
 # --------------------------------------------------------------------------------------
@@ -683,9 +692,9 @@ def gen_metapath():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "nc", "nc_train", "nc_dims", "eval", "metapath"]
+    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "nc", "nc_train", "nc_dims", "nc_latdim", "eval", "metapath"]
     if len(which) == 1:
-        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "nc": gen_nc, "nc_train": gen_nc_train, "nc_dims": gen_nc_dims, "eval": gen_eval,
+        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "nc": gen_nc, "nc_train": gen_nc_train, "nc_dims": gen_nc_dims, "nc_latdim": gen_nc_latdim, "eval": gen_eval,
          "metapath": gen_metapath}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
