@@ -124,14 +124,17 @@ class _PropagateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_sums):
         model, graphs, saved, norms = ctx.model, ctx.he_adjs, ctx.saved, ctx.norms
-        slope, L = float(model.act.negative_slope), model.args.gcn_layer
+        slope, Ls = float(model.act.negative_slope), model.layer_counts(len(graphs))
         ref = saved[0][0]
         d_sum = [torch.zeros_like(ref) if d is None else d.contiguous() for d in d_sums]
         w = [None] * len(graphs)
         planes_out, planes_in = _plane_flags(graphs)
-        for l in range(L, 0, -1):
+        for l in range(max(Ls), 0, -1):
             tasks = []
             for g, graph in enumerate(graphs):
+                L = Ls[g]
+                if l > L:
+                    continue
                 out = torch.empty_like(ref)
                 flags = DG_BWD_NORM_FEED | (DG_BWD_SAVED_PRESCALED if l < L else 0) | planes_out | (planes_in if l < L else 0)
                 tasks.append(ops.BwdTask(graph, w[g], saved[g][l - 1], d_sum[g], out, flags, slope, norms[g][l - 1]))
@@ -156,8 +159,6 @@ class HGDM(nn.Module):
         # latdim < 64: the tables stay 64 wide with zeros from column latdim on (transform_layer's output and the
         # classification weights are padded, under autograd: the zero columns neither change a sum nor get a gradient)
         self.n_hid = args.latdim
-        if args.gcn_layer != args.uugcn_layer:
-            raise NotImplementedError("fused forward assumes gcn_layer == uugcn_layer (the reference defaults)")
         out_dims = eval(args.dims) + [args.latdim]
         in_dims = out_dims[::-1]
         self.user_denoise_model = Denoise(in_dims, out_dims, args.d_emb_size, norm=args.norm).to(device)
@@ -173,6 +174,11 @@ class HGDM(nn.Module):
         nn.init.xavier_normal_(self.transform_layer.weight, gain=1.414)
         self.dense = nn.Linear(args.latdim, 4).to(device)
 
+    def layer_counts(self, n_graphs: int) -> List[int]:
+        """Layers per channel: he_adjs[0] goes through main_layers (--uugcn_layer), the others through helayers1 / 2
+        (--gcn_layer) -- Model.py:31-36,52-71."""
+        return [int(self.args.uugcn_layer)] + [int(self.args.gcn_layer)] * (n_graphs - 1)
+
     def propagate(self, he_adjs, embed: torch.Tensor):
         """(sum over layers for he_adjs[0], [1], [2]) -- Model.py:52-71."""
         if torch.is_grad_enabled() and embed.requires_grad:
@@ -181,16 +187,19 @@ class HGDM(nn.Module):
 
     def _propagate(self, he_adjs, embed: torch.Tensor, keep: bool):
         slope = float(self.act.negative_slope)
-        L = self.args.gcn_layer
+        Ls = self.layer_counts(len(he_adjs))
         sums = [torch.empty_like(embed) for _ in he_adjs]
         prev: List[Optional[torch.Tensor]] = [None] * len(he_adjs)
         saved = [[] for _ in he_adjs]
         norms = [[] for _ in he_adjs]
         planes_out, planes_in = _plane_flags(he_adjs)
-        for l in range(L):
-            last = l == L - 1
+        for l in range(max(Ls)):
             tasks = []
             for g, graph in enumerate(he_adjs):
+                L = Ls[g]
+                if l >= L:       # (this channel has fewer layers: Model.py:31-36)
+                    continue
+                last = l == L - 1
                 e_out = None if (last and not keep) else torch.empty_like(embed)
                 flags = (DG_IN_PRESCALED | planes_in if l > 0 else 0) | DG_OUT_NORM | (0 if last else DG_OUT_PRESCALE | planes_out)
                 if l == 0 and L >= 2:      # no running sum from the first layer; the second rebuilds it

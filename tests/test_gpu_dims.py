@@ -131,18 +131,21 @@ def _nc_model_and_fixture(name):
     adjs = [dg.CSRGraph.from_scipy(apa) for _ in range(3)]
     args = SimpleNamespace(**{**vars(dg.nc.DEFAULT_ARGS), "dims": str([int(v) for v in fx["dims"]]), "d_emb_size": int(fx["d_emb_size"][0]),
                               "latdim": int(fx["latdim"][0]) if "latdim" in fx.files else 64})
+    if "layers" in fx.files:
+        args.gcn_layer, args.uugcn_layer = int(fx["layers"][0]), int(fx["layers"][1])
     model = dg.nc.HGDM(features.shape[1], args).train()     # (the reference's NC program never leaves training mode)
-    assert not model.user_denoise_model.fused
+    assert model.user_denoise_model.fused == (name == "nc_dblp_layers.npz")
     with torch.no_grad():
         for nm, prm in model.named_parameters():
             prm.copy_(dev(fx["param_" + nm.replace(".", "_")]))
     return model, fx, NA, adjs, features
 
 
-@pytest.mark.parametrize("name, n_tensors", [("nc_dblp_dims.npz", 14), ("nc_dblp_latdim.npz", 10)])
+@pytest.mark.parametrize("name, n_tensors", [("nc_dblp_dims.npz", 14), ("nc_dblp_latdim.npz", 10), ("nc_dblp_layers.npz", 10)])
 def test_nc_general_denoiser_golden(name, n_tensors):
-    """DiffGraph_NC with --dims '[128, 32]' --d_emb_size 10, and with --latdim 32 (64-wide zero-padded tables, as in
-    the recommendation model), against the reference's own runs on DBLP (as-coded graphs, tests/golden/nc_dblp_dims.npz /
+    """DiffGraph_NC with --dims '[128, 32]' --d_emb_size 10, with --latdim 32 (64-wide zero-padded tables, as in
+    the recommendation model), and with --gcn_layer 2 --uugcn_layer 3 (the channels then have different layer counts;
+    the denoiser is the fused one), against the reference's own runs on DBLP (as-coded graphs, tests/golden/nc_dblp_dims.npz /
     nc_dblp_latdim.npz): get_allembeds (the reverse loop layer by layer), one training step's two losses and the
     gradients of every parameter tensor, with the timesteps, noise and dropout mask torch drew for it."""
     model, fx, NA, adjs, features = _nc_model_and_fixture(name)

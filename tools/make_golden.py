@@ -545,10 +545,18 @@ def gen_nc_latdim():
     _gen_nc_variant("nc_dblp_latdim.npz", "[64]", 8, 32, [(64, 40)], [(32, 64)])
 
 
-def _gen_nc_variant(out_name, dims, d_emb_size, latdim, want_in, want_out):
+def gen_nc_layers():
+    """... and with different layer counts per channel, --gcn_layer 2 --uugcn_layer 3 (the two source channels two
+    layers, the target channel three: Model.py:31-36), otherwise the defaults."""
+    _gen_nc_variant("nc_dblp_layers.npz", "[64]", 8, 64, [(64, 72)], [(64, 64)], gcn_layer=2, uugcn_layer=3)
+
+
+def _gen_nc_variant(out_name, dims, d_emb_size, latdim, want_in, want_out, gcn_layer=None, uugcn_layer=None):
     Model = import_reference("DiffGraph_NC")
     import scipy.sparse as sp
     Model.args.dims, Model.args.d_emb_size, Model.args.latdim = dims, d_emb_size, latdim
+    if gcn_layer is not None:
+        Model.args.gcn_layer, Model.args.uugcn_layer = gcn_layer, uugcn_layer
     feats, edges, labels = load_dblp()
     NA = feats.shape[0]
     ap = edges["ap"]
@@ -566,7 +574,8 @@ def _gen_nc_variant(out_name, dims, d_emb_size, latdim, want_in, want_out):
     assert [tuple(l.weight.shape) for l in dn.in_layers] == want_in
     assert [tuple(l.weight.shape) for l in dn.out_layers] == want_out
     model.train()
-    fx = {"dims": np.array(eval(dims)), "d_emb_size": np.array([d_emb_size]), "latdim": np.array([latdim])}
+    fx = {"dims": np.array(eval(dims)), "d_emb_size": np.array([d_emb_size]), "latdim": np.array([latdim]),
+          "layers": np.array([Model.args.gcn_layer, Model.args.uugcn_layer])}
     for nm, q in model.named_parameters():
         fx["param_" + nm.replace(".", "_")] = np64(q)
     onehot = torch.zeros(NA, 4)
@@ -692,9 +701,9 @@ def gen_metapath():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "nc", "nc_train", "nc_dims", "nc_latdim", "eval", "metapath"]
+    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "nc", "nc_train", "nc_dims", "nc_latdim", "nc_layers", "eval", "metapath"]
     if len(which) == 1:
-        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "nc": gen_nc, "nc_train": gen_nc_train, "nc_dims": gen_nc_dims, "nc_latdim": gen_nc_latdim, "eval": gen_eval,
+        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "nc": gen_nc, "nc_train": gen_nc_train, "nc_dims": gen_nc_dims, "nc_latdim": gen_nc_latdim, "nc_layers": gen_nc_layers, "eval": gen_eval,
          "metapath": gen_metapath}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
