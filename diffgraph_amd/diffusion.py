@@ -14,6 +14,7 @@ Differences a caller can see:
     through the HIP dense-layer kernels (dg_linear_fwd / dg_linear_wgrad, csrc/linear.hip), the elementwise steps
     between them (normalise, dropout, tanh, the loss) as torch device ops under autograd.  Correct for every
     configuration the reference accepts at latdim <= 64; only the default shape is tuned.
+  * `--latdim` above 64: see diffgraph_amd/wide.py (column blocks through the propagation kernel, the rest in torch).
   * `--latdim` below 64 (params.py:14): the embedding tables stay 64 floats wide with zeros from column latdim on
     (the propagation, the loss head and the evaluation kernels are built for that width, and zero columns change
     none of their sums); a denoiser of in_dims[0] = latdim takes such rows, works on their first latdim columns layer
@@ -57,9 +58,9 @@ class Denoise(nn.Module):
     def __init__(self, in_dims, out_dims, emb_size, norm=False, dropout=0.5):
         super().__init__()
         in_dims, out_dims = list(in_dims), list(out_dims)
-        if len(in_dims) < 2 or len(out_dims) < 2 or not 1 <= in_dims[0] <= DG_D or out_dims[-1] != in_dims[0] or emb_size < 1:
-            raise NotImplementedError(f"the embedding tables are {DG_D} wide: a denoiser takes and returns rows of one width "
-                                      f"(latdim) of at most {DG_D}, got in_dims {in_dims}, out_dims {out_dims}")
+        if len(in_dims) < 2 or len(out_dims) < 2 or in_dims[0] < 1 or out_dims[-1] != in_dims[0] or emb_size < 1:
+            raise NotImplementedError(f"a denoiser takes and returns rows of one width (latdim), got in_dims {in_dims}, "
+                                      f"out_dims {out_dims}")
         self.in_dims, self.out_dims = in_dims, out_dims
         self.width = in_dims[0]             # latdim: the columns of a row that carry values
         self.time_emb_dim = emb_size

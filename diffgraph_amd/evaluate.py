@@ -59,9 +59,13 @@ def all_rank_topk(usrEmbeds: torch.Tensor, itmEmbeds: torch.Tensor, users: torch
     """(values, topLocs) of t.topk(t.mm(usrEmbeds[users], itmEmbeds.T) * (1 - trnMask) - trnMask * 1e8, topk)
     (main.py:157-158) for int64 `users` on the GPU; topLocs int32 [len(users), topk]."""
     for nm, t in (("usrEmbeds", usrEmbeds), ("itmEmbeds", itmEmbeds)):
-        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or not 1 <= t.shape[1] <= DG_D \
-                or t.shape[1] != usrEmbeds.shape[1]:
-            raise DiffGraphHipError(f"{nm}: expected a float32 GPU tensor [rows, latdim <= {DG_D}], both of one width")
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] < 1 or t.shape[1] != usrEmbeds.shape[1]:
+            raise DiffGraphHipError(f"{nm}: expected a float32 GPU tensor [rows, latdim], both of one width")
+    if usrEmbeds.shape[1] > DG_D:    # wider than the scoring kernel's rows: torch's mm + topk over mask rows built on the device
+        from . import wide
+        if usrEmbeds.shape[0] != data.n_user or itmEmbeds.shape[0] != data.n_item:
+            raise DiffGraphHipError("embedding tables do not match the interaction matrices")
+        return wide.all_rank_topk(usrEmbeds, itmEmbeds, users, data.trn_rowptr, data.trn_col, topk)
     if usrEmbeds.shape[1] < DG_D:    # a narrower latent space: zeros behind the rows add nothing to a score
         pad = (0, DG_D - usrEmbeds.shape[1])
         usrEmbeds, itmEmbeds = torch.nn.functional.pad(usrEmbeds, pad), torch.nn.functional.pad(itmEmbeds, pad)

@@ -215,8 +215,11 @@ class HGDM(nn.Module):
     def __init__(self, data_handler, args=None, device="cuda"):
         super().__init__()
         self.args = args = args or DEFAULT_ARGS
-        if not 1 <= args.latdim <= DG_D:
-            raise NotImplementedError(f"the kernels' rows are {DG_D} floats wide: latdim must be in 1..{DG_D} (got {args.latdim})")
+        if args.latdim < 1:
+            raise ValueError(f"latdim must be positive (got {args.latdim})")
+        # latdim > 64: the table has its true width and the model runs through diffgraph_amd.wide (column blocks of 64
+        # through the propagation kernel, what couples them in torch)
+        self.wide = args.latdim > DG_D
         self.n_user, self.n_item = data_handler.userNum, data_handler.itemNum
         bm = data_handler.behavior_mats
         self.behavior_mats = [bm[k] for k in sorted(bm)] if isinstance(bm, dict) else list(bm)
@@ -227,7 +230,7 @@ class HGDM(nn.Module):
         # kernel on the path sums over a row's columns or treats them alike, the zero columns of the denoisers' outputs
         # and of the noise (cal_loss_vector) keep their gradient at exactly zero, and Adam leaves a zero with a zero
         # gradient where it is.
-        table = torch.zeros(self.n_user + self.n_item, DG_D, device=device)
+        table = torch.zeros(self.n_user + self.n_item, max(DG_D, self.n_hid), device=device)
         nn.init.xavier_uniform_(table[: self.n_user, : self.n_hid])
         nn.init.xavier_uniform_(table[self.n_user:, : self.n_hid])
         self.embedding_table = nn.Parameter(table)
@@ -351,6 +354,9 @@ class HGDM(nn.Module):
 
     def propagate(self, e0: torch.Tensor):
         """Returns (ui_embeddings [N,64], all_heter_embeddings [N,64])  (Model.py:61-87)."""
+        if self.wide:
+            from . import wide
+            return wide.propagate([self.target_adj] + self.behavior_mats, e0, self.n_layers, float(self.act.negative_slope))
         if torch.is_grad_enabled() and e0.requires_grad:
             return _PropagateFn.apply(e0, self)
         ui, het, _ = self._propagate(e0.detach().contiguous(), keep=False)
@@ -458,7 +464,7 @@ class HGDM(nn.Module):
         """(target_user, target_item, heter_user, heter_item), each [rows, latdim] (Model.py:53-92)."""
         ui, het = self.propagate(self.embedding_table)
         nu, L = self.n_user, self.n_hid
-        if L != DG_D:
+        if L < DG_D:
             return ui[:nu, :L], ui[nu:, :L], het[:nu, :L], het[nu:, :L]
         return ui[:nu], ui[nu:], het[:nu], het[nu:]
 
@@ -475,6 +481,9 @@ class HGDM(nn.Module):
         dp = self.diffusion_process
         dev, n = self.embedding_table.device, self.n_user + self.n_item
         denoisers = [self.usr_denoiser, self.item_denoiser]
+        if self.wide:
+            from . import wide
+            return wide.cal_loss(self, ancs, poss, negs, ts_u, noise_u, ts_i, noise_i, keep_u, keep_i)
         if not all(dn.fused for dn in denoisers):
             return self._cal_loss_layers(ancs, poss, negs, ts_u, noise_u, ts_i, noise_i, keep_u, keep_i)
         if validate is None:   # caller-supplied timesteps are range-checked (one host sync) unless the caller vouches for them
@@ -530,4 +539,4 @@ class HGDM(nn.Module):
         denoised_u, denoised_i = dp.p_sample_many([(self.usr_denoiser, het[:nu]), (self.item_denoiser, het[nu:])],
                                                   self.args.sampling_steps)
         pu, pi = ui[:nu] + denoised_u, ui[nu:] + denoised_i
-        return (pu, pi) if L == DG_D else (pu[:, :L], pi[:, :L])
+        return (pu, pi) if L >= DG_D else (pu[:, :L], pi[:, :L])

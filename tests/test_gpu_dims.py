@@ -102,9 +102,9 @@ def test_general_denoiser_trains_through_coach_steps():
     assert all(not torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
 
 
-def test_wider_rows_are_refused_with_a_clear_message():
-    with pytest.raises(NotImplementedError, match="64 wide"):
-        dg.Denoise([128, 64], [64, 128], 8)
+def test_a_denoiser_of_two_widths_is_refused_with_a_clear_message():
+    with pytest.raises(NotImplementedError, match="one width"):
+        dg.Denoise([128, 64], [64, 32], 8)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

@@ -330,6 +330,11 @@ def gen_rec_latdim():
     _gen_rec_variant("rec_tiny_latdim.npz", "[64]", 8, 32, [(64, 40)], [(32, 64)])
 
 
+def gen_rec_latdim128():
+    """... and with a wider one, --latdim 128 (embeddings [n, 128], in_layers 136->64, out_layers 64->128)."""
+    _gen_rec_variant("rec_tiny_latdim128.npz", "[64]", 8, 128, [(64, 136)], [(128, 64)])
+
+
 def _gen_rec_variant(out_name, dims, d_emb_size, latdim, want_in, want_out):
     Model = import_reference("DiffGraph-Rec")
     from diffgraph_amd import data as dgdata
@@ -701,9 +706,9 @@ def gen_metapath():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "nc", "nc_train", "nc_dims", "nc_latdim", "nc_layers", "eval", "metapath"]
+    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "rec_latdim128", "nc", "nc_train", "nc_dims", "nc_latdim", "nc_layers", "eval", "metapath"]
     if len(which) == 1:
-        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "nc": gen_nc, "nc_train": gen_nc_train, "nc_dims": gen_nc_dims, "nc_latdim": gen_nc_latdim, "nc_layers": gen_nc_layers, "eval": gen_eval,
+        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "rec_latdim128": gen_rec_latdim128, "nc": gen_nc, "nc_train": gen_nc_train, "nc_dims": gen_nc_dims, "nc_latdim": gen_nc_latdim, "nc_layers": gen_nc_layers, "eval": gen_eval,
          "metapath": gen_metapath}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
