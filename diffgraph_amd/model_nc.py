@@ -154,8 +154,10 @@ class HGDM(nn.Module):
     def __init__(self, f_dim, args=None, device="cuda"):
         super().__init__()
         self.args = args = args or DEFAULT_ARGS
-        if not 1 <= args.latdim <= DG_D:
-            raise NotImplementedError(f"the kernels' rows are {DG_D} floats wide: latdim must be in 1..{DG_D} (got {args.latdim})")
+        if args.latdim < 1:
+            raise ValueError(f"latdim must be positive (got {args.latdim})")
+        # latdim > 64: through diffgraph_amd.wide (column blocks of 64 through the propagation kernel, the rest in torch)
+        self.wide = args.latdim > DG_D
         # latdim < 64: the tables stay 64 wide with zeros from column latdim on (transform_layer's output and the
         # classification weights are padded, under autograd: the zero columns neither change a sum nor get a gradient)
         self.n_hid = args.latdim
@@ -231,6 +233,11 @@ class HGDM(nn.Module):
         return s1, s2, target
 
     def forward(self, he_adjs, feature_list, is_training=True):
+        if self.wide:
+            from . import wide
+            embed = _LinearFn.apply(feature_list, self.transform_layer.weight, self.transform_layer.bias)
+            target, s1, s2 = wide.nc_propagate(he_adjs, embed, self.layer_counts(len(he_adjs)), float(self.act.negative_slope))
+            return s1, s2, target
         s1, s2, target = self._forward_wide(he_adjs, feature_list)
         if self.n_hid != DG_D:
             L = self.n_hid
@@ -242,6 +249,9 @@ class HGDM(nn.Module):
         """`ts` / `noise` / `keep_mask`: the draws of training_losses2 handed in instead of drawn (`drop_seed`, int64[1]
         on the device: the key the kernels draw the dropout mask from when no mask is given); `validate=False` skips
         the range check of caller-supplied timesteps (a host synchronisation a recorded step cannot have)."""
+        if self.wide:
+            from . import wide
+            return wide.nc_cal_loss(self, ancs, label, he_adjs, initial_feature, ts, noise, keep_mask)
         s1, s2, target_embedding = self._forward_wide(he_adjs, initial_feature)
         source_embeddings = s1 + s2
         # training_losses2 before its [batch] gather: the head below gathers the batch rows of everything at once
@@ -264,6 +274,10 @@ class HGDM(nn.Module):
         return all_embeddings[ancs]
 
     def get_allembeds(self, he_adjs, initial_feature):  # Model.py:100-108
+        if self.wide:
+            s1, s2, target_embedding = self.forward(he_adjs, initial_feature)
+            all_embeddings = target_embedding + self.diffusion_model.p_sample(self.user_denoise_model, s1 + s2, self.args.sampling_steps)
+            return all_embeddings, self.dense(all_embeddings)
         s1, s2, target_embedding = self._forward_wide(he_adjs, initial_feature)
         source_embeddings = s1 + s2
         diff_embeddings = self.diffusion_model.p_sample(self.user_denoise_model, source_embeddings, self.args.sampling_steps)

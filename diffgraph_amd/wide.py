@@ -94,3 +94,30 @@ def all_rank_topk(usr: torch.Tensor, itm: torch.Tensor, users: torch.Tensor, trn
         vals.append(v)
         idx.append(i.to(torch.int32))
     return torch.cat(vals), torch.cat(idx)
+
+
+# ------------------------------------------------------------------------------------------------ DiffGraph_NC
+def nc_propagate(he_adjs: Sequence, embed: torch.Tensor, layer_counts: Sequence[int], slope: float) -> List[torch.Tensor]:
+    """The three layer sums of DiffGraph_NC's HGDM.forward (Model.py:52-71) for embed [n, latdim], latdim any: the
+    NORMALISED activation feeds the next layer; channel c runs layer_counts[c] layers."""
+    n, L = embed.shape
+    B = -(-L // DG_D)
+    x0 = embed if L == B * DG_D else F.pad(embed, (0, B * DG_D - L))
+    sums = []
+    for g, count in zip(he_adjs, layer_counts):
+        acc = cur = x0
+        for _ in range(count):
+            blocks = [_SpmmFn.apply(cur[:, DG_D * b: DG_D * (b + 1)], g, slope) for b in range(B)]
+            cur = F.normalize(torch.cat(blocks, dim=1), p=2, dim=1)
+            acc = acc + cur
+        sums.append(acc[:, :L])
+    return sums
+
+
+def nc_cal_loss(model, ancs, label, he_adjs, initial_feature, ts=None, noise=None, keep_mask=None):
+    """DiffGraph_NC's HGDM.cal_loss (Model.py:75-89): (nll_loss, diff_loss)."""
+    s1, s2, target = model.forward(he_adjs, initial_feature)
+    ancs = ancs.long()
+    row_loss, diffused = model.diffusion_model.training_losses_rows(model.user_denoise_model, target, s1 + s2, ts, noise, keep_mask)
+    scores = F.log_softmax(model.dense(target + diffused), dim=1)
+    return F.nll_loss(scores[ancs], torch.argmax(label[ancs], dim=-1)), row_loss[ancs].mean()

@@ -131,10 +131,6 @@ def test_narrow_latent_coach_epochs(use_graph):
     assert 0.0 <= res["Recall"] <= 1.0 and len(c.metrics["TestRecall"]) == 2
 
 
-def test_wider_latent_is_refused_by_the_nc_model_with_a_clear_message():
-    args = SimpleNamespace(**{**vars(dg.nc.DEFAULT_ARGS), "latdim": 128})
-    with pytest.raises(NotImplementedError, match="1..64"):
-        dg.nc.HGDM(334, args)
 
 
 # ------------------------------------------------------------------------------------------------ latdim 128

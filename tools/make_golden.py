@@ -550,6 +550,11 @@ def gen_nc_latdim():
     _gen_nc_variant("nc_dblp_latdim.npz", "[64]", 8, 32, [(64, 40)], [(32, 64)])
 
 
+def gen_nc_latdim128():
+    """... and with --latdim 128 (transform_layer 334->128, in_layers 136->64, out_layers 64->128, dense 128->4)."""
+    _gen_nc_variant("nc_dblp_latdim128.npz", "[64]", 8, 128, [(64, 136)], [(128, 64)])
+
+
 def gen_nc_layers():
     """... and with different layer counts per channel, --gcn_layer 2 --uugcn_layer 3 (the two source channels two
     layers, the target channel three: Model.py:31-36), otherwise the defaults."""
@@ -589,6 +594,10 @@ def _gen_nc_variant(out_name, dims, d_emb_size, latdim, want_in, want_out, gcn_l
     fx["cl_ancs"] = np64(ancs)
     with torch.no_grad():
         emb, scores = model.get_allembeds(adjs, features)
+        if latdim > 64:      # (a sample of the rows keeps the file small)
+            rows = torch.sort(torch.randperm(NA, generator=torch.Generator().manual_seed(3))[:512]).values
+            fx["rows"] = np64(rows)
+            emb, scores = emb[rows], scores[rows]
         fx["all_embeddings"], fx["scores"] = np64(emb), np64(scores)
     model.zero_grad()
     with Recorder() as rec:
@@ -706,9 +715,9 @@ def gen_metapath():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "rec_latdim128", "nc", "nc_train", "nc_dims", "nc_latdim", "nc_layers", "eval", "metapath"]
+    which = sys.argv[1:] or ["rec", "rec_train", "rec_dims", "rec_latdim", "rec_latdim128", "nc", "nc_train", "nc_dims", "nc_latdim", "nc_latdim128", "nc_layers", "eval", "metapath"]
     if len(which) == 1:
-        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "rec_latdim128": gen_rec_latdim128, "nc": gen_nc, "nc_train": gen_nc_train, "nc_dims": gen_nc_dims, "nc_latdim": gen_nc_latdim, "nc_layers": gen_nc_layers, "eval": gen_eval,
+        {"rec": gen_rec, "rec_train": gen_rec_train, "rec_dims": gen_rec_dims, "rec_latdim": gen_rec_latdim, "rec_latdim128": gen_rec_latdim128, "nc": gen_nc, "nc_train": gen_nc_train, "nc_dims": gen_nc_dims, "nc_latdim": gen_nc_latdim, "nc_latdim128": gen_nc_latdim128, "nc_layers": gen_nc_layers, "eval": gen_eval,
          "metapath": gen_metapath}[which[0]]()
     else:
         for w in which:  # the two programs share module names (Model, params, Utils): one process each
