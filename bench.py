@@ -2,13 +2,13 @@
 """bench.py -- DiffGraph hot path on MI355X: SpMM edges/s + achieved HBM GB/s per propagation layer.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tmall|ijcai|retail_rocket|industry]
-    python bench.py --workload predict_ijcai|nc_dblp                                   (the other BASELINE configs)
+    python bench.py --workload predict_ijcai|nc_dblp                                   (the other benchmark configurations)
     python bench.py --workload eval_tmall|eval_ijcai|negsample_tmall|metapath_dblp     (neighbouring stages)
 
 One JSON line on stdout (rank 0).  A "step" is one pass of the hot path over one synthetic
 batch: HGDM.cal_loss -- (1+B)*L fused propagation launches, q_sample + denoiser + SNR loss for
-users and items, BPR glue.  At N=1 the workload is the Tmall-shaped graph (BASELINE.json
-configs[1]); with N>1 ranks it is the Industry-shaped graph row-sharded over the ranks.
+users and items, BPR glue.  At N=1 the workload is the Tmall-shaped graph (the configuration the
+headline metric is quoted on); with N>1 ranks it is the Industry-shaped graph row-sharded over the ranks.
 Inputs are resident in HBM before the timed region.  `value` = edges gathered by all SpMM
 launches of the K steps / wall time (max over ranks).
 """
