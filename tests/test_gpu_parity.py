@@ -1000,6 +1000,29 @@ def test_sharded_lds_graphs_split_layer_calls():
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
 
 
+def test_sharded_forward_recorded_as_a_graph_replays_bit_for_bit():
+    """ShardedRecPropagation.capture: the prepared launches of a forward pass (and its exchange -- here the stand-in of a
+    one-rank job) recorded as one HIP graph; replays over a changed table equal the eager pass bit for bit, and a pass
+    without reused buffers cannot be recorded."""
+    from diffgraph_amd.dist import HipBackend, ShardedRecPropagation
+    nu, ni = 9000, 37
+    inter = [dgdata.synth_interactions(nu, ni, m, seed) for m, seed in ((30000, 1), (80000, 2), (12000, 3))]
+    e0 = torch.cat([T(dgdata.xavier_uniform(nu, 64, seed=0)), T(dgdata.xavier_uniform(ni, 64, seed=1))]).to(DEV)
+    plain = ShardedRecPropagation(inter, nu, ni, 0, 1, HipBackend(torch.device(DEV)))
+    with pytest.raises(ValueError, match="reuse_buffers"):
+        plain.capture(e0)
+    prop = ShardedRecPropagation(inter, nu, ni, 0, 1, HipBackend(torch.device(DEV)), reuse_buffers=True)
+    graph, (ui, het) = prop.capture(e0)
+    e0.mul_(0.75)
+    want = [t.clone() for t in plain.forward(e0)]
+    for _ in range(2):
+        ui.fill_(float("nan"))
+        het.fill_(float("nan"))
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ui, want[0]) and torch.equal(het, want[1])
+
+
 @pytest.mark.parametrize("nu,ni", [(3000, 20), (1300, 7), (40000, 383)])
 def test_shared_layer_sum_flag_is_checked(nu, ni):
     """DG_ACC_SHARED: only with DG_ROWS_FULL_ONLY on the last layer of graphs with one side in LDS, tasks 1.. naming one
