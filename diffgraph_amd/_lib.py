@@ -62,7 +62,8 @@ class LossTask(C.Structure):
                 ("g_row_loss", C.c_void_p), ("g_out", C.c_void_p), ("d_target_add", C.c_void_p), ("d_x_start", C.c_void_p),
                 ("d_target", C.c_void_p), ("dout_tot", C.c_void_p), ("hid", C.c_void_p), ("dpre", C.c_void_p),
                 ("xn", C.c_void_p), ("keep_mask", C.c_void_p), ("drop_seed", C.c_void_p), ("drop_p", C.c_float),
-                ("wg_tab", C.c_void_p), ("wg_partials", C.c_void_p)]
+                ("wg_tab", C.c_void_p), ("wg_partials", C.c_void_p), ("rows", C.c_void_p), ("n_rows", C.c_void_p),
+                ("rows_cap", C.c_int32)]
 
 
 class WgradTask(C.Structure):
@@ -160,6 +161,7 @@ SIGNATURES = {
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dg_adam_step_prepared": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "dg_active_rows": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p] * 5),
     "dg_rec_head_fwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32] * 3 + [C.c_double, C.c_double, C.c_int32] + [C.c_void_p] * 4),
     "dg_rec_head_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "dg_linear_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p, C.c_void_p]),

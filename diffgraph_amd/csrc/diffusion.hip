@@ -62,7 +62,25 @@ struct dn_task {
   uint32_t drop_thr, drop_stream;     // kept iff the element's random byte >= drop_thr; stream = task number
   int64_t n;
   int32_t n_steps, norm, blk_begin;
+  // rows != NULL: the task's workgroups take the table rows rows[0 .. *n_rows) (at most rows_cap of them) instead of
+  // rows 0 .. n: slot s of the launch is table row rows[s]
+  const int32_t *rows, *n_rows;
+  int32_t rows_cap;
 };
+
+// The table row of a launch slot, and whether the slot holds one.  *none: the workgroup's first slot is already past
+// the listed rows (the same for every thread of the workgroup).
+__device__ __forceinline__ int64_t slot_row(const dn_task &T, int64_t slot, int64_t block_first, bool &valid, bool &none) {
+  none = false;
+  if (T.rows == nullptr) {
+    valid = slot < T.n;
+    return slot;
+  }
+  const int64_t cnt = min((int64_t)T.n_rows[0], (int64_t)T.rows_cap);
+  none = block_first >= cnt;
+  valid = slot < cnt;
+  return valid ? (int64_t)T.rows[slot] : 0;
+}
 
 struct dn_batch {
   dn_task t[kDnMaxTasks];
@@ -213,8 +231,10 @@ __global__ __launch_bounds__(kThreads, 2) void denoise_kernel(const dn_batch bat
     if (b >= batch.t[k].blk_begin) ti_ = k;
   const dn_task &T = batch.t[ti_];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int64_t row = ((int64_t)(b - T.blk_begin) * kWavesPerBlock + wave) * kRowsPerWave + j;
-  const bool valid = row < T.n;
+  bool valid, none;
+  const int64_t first = (int64_t)(b - T.blk_begin) * kRowsPerBlock;
+  const int64_t row = slot_row(T, first + wave * kRowsPerWave + j, first, valid, none);
+  if (none) return;   // (the whole workgroup: a row list shorter than its capacity)
   const bool norm = T.norm != 0;
 
   // the row tile is asked for before the weight images are staged: its way from HBM overlaps the staging
@@ -428,8 +448,16 @@ __global__ __launch_bounds__(kThreads, 2) void loss_bwd_kernel(const dn_batch ba
     if (b >= batch.t[k].blk_begin) ti_ = k;
   const dn_task &T = batch.t[ti_];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int64_t row = ((int64_t)(b - T.blk_begin) * kWavesPerBlock + wave) * kRowsPerWave + j;
-  const bool valid = row < T.n;
+  bool valid, none;
+  const int64_t first = (int64_t)(b - T.blk_begin) * kRowsPerBlock;
+  const int64_t row = slot_row(T, first + wave * kRowsPerWave + j, first, valid, none);
+  if (none) {   // (the whole workgroup) no rows: its partial result of the weight gradients is zero
+    if (T.wg_partials != nullptr) {
+      float *P = T.wg_partials + (size_t)(b - T.blk_begin) * dg_wg::kPartFloats;
+      for (int i = threadIdx.x; i < dg_wg::kPartFloats; i += kThreads) P[i] = 0.f;
+    }
+    return;
+  }
   const int64_t ro = row * DG_D;
   int t = 0;
   if (valid) t = min(max((int)T.t[row], 0), T.n_steps - 1);
@@ -899,6 +927,12 @@ int fill_loss_task(const char *who, const dg_loss_task &t, int32_t n_steps, int3
   k.w_in = t.dn->w_in; k.w_out = t.dn->w_out; k.b_out = t.dn->b_out; k.time_bias = t.time_bias;
   k.x = t.x_start; k.noise = t.noise; k.target = t.target; k.t = t.ts; k.sqrt_ac = sqrt_ac; k.sqrt_1mac = sqrt_1mac;
   k.loss_w = loss_w; k.n = t.n; k.n_steps = n_steps; k.norm = t.dn->norm;
+  if (t.rows != nullptr) {
+    if (!t.n_rows || t.rows_cap <= 0 || t.rows_cap > t.n)
+      return dg_fail(DG_ERR_ARG, "%s: a row list needs its DEVICE count and a capacity in [1, n] (got %d, n = %lld)", who,
+                     t.rows_cap, (long long)t.n);
+    k.rows = t.rows; k.n_rows = t.n_rows; k.rows_cap = t.rows_cap;
+  }
   if ((rc = set_dropout(who, t.keep_mask, t.drop_seed, t.drop_p, k))) return rc;
   if (!bwd) {
     if (!t.out || !t.row_loss) return dg_fail(DG_ERR_ARG, "%s: NULL output", who);
@@ -931,7 +965,7 @@ int loss_batched(const char *who, const dg_loss_task *tasks, int32_t n_tasks, in
     if (tasks[i].n == 0) continue;
     k.blk_begin = (int32_t)blocks;
     k.drop_stream = (uint32_t)i;
-    blocks += (tasks[i].n + kRowsPerBlock - 1) / kRowsPerBlock;
+    blocks += ((tasks[i].rows ? (int64_t)tasks[i].rows_cap : tasks[i].n) + kRowsPerBlock - 1) / kRowsPerBlock;
     batch.t[batch.n_tasks++] = k;
   }
   if (batch.n_tasks == 0) return 0;

@@ -260,7 +260,67 @@ __global__ __launch_bounds__(16 * kHeavyRuns) void head_heavy_kernel(int n_batch
   }
 }
 
+// flags[row] = 1 for every table row a batch entry names (users: ancs; items, behind the users: poss and negs)
+__global__ __launch_bounds__(256) void mark_rows_kernel(const int64_t *__restrict__ ancs, const int64_t *__restrict__ poss,
+                                                        const int64_t *__restrict__ negs, int n_batch, int n_user, int n_item,
+                                                        int *__restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * n_batch) return;
+  const int which = i / n_batch, b = i - which * n_batch;
+  const int64_t idx = which == 0 ? ancs[b] : which == 1 ? poss[b] : negs[b];
+  if ((uint64_t)idx >= (uint64_t)(which == 0 ? n_user : n_item)) return;
+  flags[(which == 0 ? 0 : n_user) + (int)idx] = 1;   // (several entries may name a row: the same value)
+}
+
+// The flagged rows of the user table and of the item table, each as an ascending list of row numbers inside its table
+// and a count.  A workgroup takes 1024 consecutive flags of one table (one per thread): it first counts the flags set
+// before its run -- every workgroup on its own, a few coalesced reads per thread instead of a scan across workgroups --
+// then numbers its own by ballots and writes them behind.  The table's last workgroup also writes the count.
+__global__ __launch_bounds__(1024) void compact_rows_kernel(const int *__restrict__ flags, int n_user, int n_item, int blocks_u,
+                                                            int *__restrict__ rows_u, int cap_u, int *__restrict__ rows_i,
+                                                            int cap_i, int *__restrict__ counts) {
+  __shared__ int wave_sum[16], before_sum[16];
+  const bool items = (int)blockIdx.x >= blocks_u;
+  const int *f = flags + (items ? n_user : 0);
+  const int len = items ? n_item : n_user, cap = items ? cap_i : cap_u;
+  int *rows = items ? rows_i : rows_u;
+  const int chunk0 = ((int)blockIdx.x - (items ? blocks_u : 0)) * 1024;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int before = 0;
+  for (int r = threadIdx.x; r < chunk0; r += 1024) before += f[r] != 0;
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+  const int r = chunk0 + (int)threadIdx.x;
+  const bool mine = r < len && f[r] != 0;
+  const unsigned long long bal = __ballot(mine);
+  if (lane == 0) { before_sum[wave] = before; wave_sum[wave] = __popcll(bal); }
+  __syncthreads();
+  int at = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    at += before_sum[w];
+    if (w < wave) at += wave_sum[w];
+    total += before_sum[w] + wave_sum[w];
+  }
+  at += __popcll(bal & ((1ull << lane) - 1ull));
+  if (mine && at < cap) rows[at] = r;
+  if (threadIdx.x == 0 && chunk0 + 1024 >= len) counts[items ? 1 : 0] = min(total, cap);
+}
+
 }  // namespace
+
+extern "C" int dg_active_rows(const int64_t *ancs, const int64_t *poss, const int64_t *negs, int32_t n_batch, int32_t n_user,
+                              int32_t n_item, int32_t *flags, int32_t *rows_u, int32_t *rows_i, int32_t *counts, void *stream) {
+  if (!ancs || !poss || !negs || !flags || !rows_u || !rows_i || !counts) return dg_fail(DG_ERR_ARG, "dg_active_rows: NULL argument");
+  if (n_batch <= 0 || n_batch > kMaxBatch) return dg_fail(DG_ERR_SIZE, "dg_active_rows: n_batch must be in [1,%d] (got %d)", kMaxBatch, n_batch);
+  if (n_user <= 0 || n_item <= 0) return dg_fail(DG_ERR_ARG, "dg_active_rows: bad sizes");
+  DG_HIP(hipMemsetAsync(flags, 0, ((size_t)n_user + (size_t)n_item) * sizeof(int32_t), (hipStream_t)stream));
+  hipLaunchKernelGGL(mark_rows_kernel, dim3((3 * n_batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, ancs, poss, negs, n_batch,
+                     n_user, n_item, flags);
+  const int blocks_u = (n_user + 1023) / 1024, blocks_i = (n_item + 1023) / 1024;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(blocks_u + blocks_i), dim3(1024), 0, (hipStream_t)stream, flags, n_user, n_item, blocks_u,
+                     rows_u, n_batch, rows_i, 2 * n_batch, counts);
+  DG_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int dg_rec_head_fwd(const float *ui, const float *out_u, const float *out_i, const double *row_loss_u,
                                const double *row_loss_i, const int64_t *ancs, const int64_t *poss, const int64_t *negs,

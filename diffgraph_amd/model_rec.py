@@ -13,6 +13,7 @@ next one, and adds the L2-normalised activation into that graph's running sum.
 """
 from __future__ import annotations
 
+import os
 from contextlib import contextmanager
 from dataclasses import replace
 from types import SimpleNamespace
@@ -168,8 +169,12 @@ class _RecLossFn(torch.autograd.Function):
         ui, het = ui.contiguous(), het.contiguous()
         drop_p, keep_mask, drop_seed = drop
         spans = []
-        for dn, begin, n in ((model.usr_denoiser, 0, nu), (model.item_denoiser, nu, model.n_item)):
-            spans.append(ops.LossSpan(dn.params(bool(dn.norm)), begin, n, drop_p))   # (time-bias tables: cal_loss_vector)
+        # only the rows the batch names go through the denoisers (cal_loss_vector listed them beside the propagation):
+        # diff_loss is read at [ancs] / [poss] and the outputs at [ancs], [poss], [negs] alone (Model.py:96-104)
+        act, model._active = model._active, None
+        for k, (dn, begin, n) in enumerate(((model.usr_denoiser, 0, nu), (model.item_denoiser, nu, model.n_item))):
+            rows = {} if act is None else dict(rows=act[1 + k], n_rows=act[3][k: k + 1])
+            spans.append(ops.LossSpan(dn.params(bool(dn.norm)), begin, n, drop_p, **rows))   # (time-bias tables: cal_loss_vector)
         sa = gd._dev("sqrt_alphas_cumprod", dev) if gd.noise_scale != 0 else None
         sb = gd._dev("sqrt_one_minus_alphas_cumprod", dev) if gd.noise_scale != 0 else None
         lw = gd._dev("loss_weight", dev, torch.float64)
@@ -184,21 +189,23 @@ class _RecLossFn(torch.autograd.Function):
             results, ent_f = ops.rec_head_fwd(ui, out[:nu], out[nu:], row_loss[:nu], row_loss[nu:], ancs, poss, negs, nu,
                                               float(args.batch), float(args.reg))
         ctx.save_for_backward(ui, het, noise if noise is not None else het, ts, out, ancs, poss, negs, ent_f)
-        ctx.aux = (model, spans, sa, sb, lw, keep_mask, drop_seed)
+        ctx.aux = (model, spans, sa, sb, lw, keep_mask, drop_seed, act)
         return results
 
     @staticmethod
     def backward(ctx, g):
         ui, het, noise, ts, out, ancs, poss, negs, ent_f = ctx.saved_tensors
-        model, spans, sa, sb, lw, keep_mask, drop_seed = ctx.aux
+        model, spans, sa, sb, lw, keep_mask, drop_seed, act = ctx.aux
         gd, args, nu = model.diffusion_process, model.args, model.n_user
         head_buf, model._head_buf = model._head_buf, None     # cleared beside the forward propagation (cal_loss_vector)
+        dhet_buf, model._dhet_buf = model._dhet_buf, None     # (so was this one: d het of the rows outside the batch is zero)
         d_ui_head, d_out, d_rl = ops.rec_head_bwd(ui, out[:nu], out[nu:], ancs, poss, negs, nu, float(args.batch),
                                                   float(args.reg), ent_f, g.contiguous(), full=True, buffer=head_buf)
         # one launch for both diffusion losses; it also sums the weight gradients' operands over its 128-row strips
+        listed = {} if act is None else dict(d_x_start_out=dhet_buf, d_target_out=d_ui_head)   # (d ui written over the head's)
         d_het, d_ui, partials = ops.diffusion_loss_bwd_spans(spans, ui, het, noise, ts, sa, sb, lw, d_rl, d_out,
                                                              d_target_add=d_ui_head, keep_mask=keep_mask,
-                                                             drop_seed=drop_seed, fused_wgrad=True)
+                                                             drop_seed=drop_seed, fused_wgrad=True, **listed)
         jobs = [(sp.dn, part) for sp, part in zip(spans, partials)]
         if model.side_join_deferred:
             # a caller that promises run_late_side_work() before it touches the gradients (training_step): the strips'
@@ -249,6 +256,9 @@ class HGDM(nn.Module):
         self._side_pending: list = []
         self._late_side: list = []
         self._head_buf: Optional[torch.Tensor] = None
+        self._dhet_buf: Optional[torch.Tensor] = None
+        self._active = None
+        self.loss_on_batch_rows = os.environ.get("DG_LOSS_ALL_ROWS") != "1"   # False: both denoisers over every row, as the reference runs them
         self.side_join_deferred = False
         self.side_overlap = True       # False: side_work() stays on the current stream (one kernel at a time, e.g. to time them)
         self.merge_last_step = True    # False: the backward's last propagation step runs graph by graph (see merged_last_step)
@@ -501,6 +511,10 @@ class HGDM(nn.Module):
         if dp.noise_scale != 0:
             noise = torch.empty((n, DG_D), device=dev) if need_noise else torch.cat([noise_u, noise_i]).contiguous()
         self._head_buf = ops.rec_head_bwd_buffer(n, dev, clear=False) if torch.is_grad_enabled() else None
+        ancs, poss, negs = (v.long().contiguous() for v in (ancs, poss, negs))
+        listed = self.loss_on_batch_rows and 0 < ancs.numel() <= 8192 and ancs.numel() == poss.numel() == negs.numel()
+        act = ops.active_rows_buffers(ancs.numel(), n, dev) if listed else None
+        self._dhet_buf = torch.empty((n, DG_D), device=dev) if listed and torch.is_grad_enabled() else None
         start = self.fork_point()
         ui, het = self.propagate(self.embedding_table)   # [users | items] tables: target-graph sums, behaviour sums
         # beside the propagation (launched after it, started before it): the draws and both denoisers' time-bias tables
@@ -510,12 +524,16 @@ class HGDM(nn.Module):
                                    noise if need_noise else None)
             params = [dn.params(bool(dn.norm)) for dn in denoisers]
             ops.refresh_time_bias(params, dp.steps)
+            if act is not None:
+                ops.active_rows(ancs, poss, negs, self.n_user, self.n_item, out=act)   # the rows the batch names
             if torch.is_grad_enabled():
                 ops.wgrad_operand_tables(params, dp.steps)     # the backward pass's time-embedding operands
                 ops.clear_rec_head_bwd_buffer(self._head_buf, n)   # ... and the loss head's cleared gradient tables
+                if self._dhet_buf is not None:
+                    ops.clear_table(self._dhet_buf)
         self.join_side_work()
+        self._active = act
         drop = dropout_args(denoisers, keep, dev, self.draw_state[2:3])
-        ancs, poss, negs = (v.long().contiguous() for v in (ancs, poss, negs))
         weights = []
         for dn in (self.usr_denoiser, self.item_denoiser):
             weights += [dn.emb_layer.weight, dn.emb_layer.bias, dn.in_layers[0].weight, dn.in_layers[0].bias,

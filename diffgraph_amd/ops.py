@@ -487,6 +487,9 @@ class LossSpan:
     begin: int
     n: int
     drop_p: float = 0.0
+    # only these rows of the span take part (int32 row numbers inside the span, ascending, on the device) ...
+    rows: Optional[torch.Tensor] = None
+    n_rows: Optional[torch.Tensor] = None     # ... this many of them (int32[1] on the device); see active_rows()
 
 
 def new_draw_state(device, seed: Optional[int] = None) -> torch.Tensor:
@@ -548,8 +551,41 @@ def _span_tasks(spans: Sequence[LossSpan], n_steps: int, tables: dict, keep_mask
             t.drop_seed = None if drop_seed is None else drop_seed.data_ptr()
         for name, (tensor, row_bytes) in tables.items():
             setattr(t, name, None if tensor is None else tensor.data_ptr() + sp.begin * row_bytes)
+        if sp.rows is not None:
+            if sp.rows.dtype != torch.int32 or not sp.rows.is_cuda or not sp.rows.is_contiguous() or sp.n_rows is None \
+                    or sp.n_rows.dtype != torch.int32 or sp.n_rows.numel() != 1 or not 0 < sp.rows.numel():
+                raise DiffGraphHipError("a span's row list: contiguous int32 GPU vector with its int32[1] count")
+            t.rows, t.n_rows, t.rows_cap = sp.rows.data_ptr(), sp.n_rows.data_ptr(), min(sp.rows.numel(), sp.n)
         arr[k] = t
     return arr
+
+
+def active_rows_buffers(n_batch: int, n: int, device):
+    """(flags scratch int32[n], rows_u int32[B], rows_i int32[2B], counts int32[2]) for active_rows(out=...)."""
+    mk = lambda m: torch.empty(m, dtype=torch.int32, device=device)
+    return mk(n), mk(n_batch), mk(2 * n_batch), mk(2)
+
+
+def clear_table(t: torch.Tensor) -> None:
+    """Zeroes a table with the runtime's memset on the current stream (a memset node in a recorded step)."""
+    rc = _lib.load().dg_clear(t.data_ptr(), t.numel() * t.element_size(), _lib.stream_ptr(t.device))
+    _lib.check(rc, "dg_clear")
+
+
+def active_rows(ancs, poss, negs, n_user: int, n_item: int, out=None):
+    """The table rows a batch of HGDM.cal_loss names (Model.py:96-104): (rows_u int32[B] = the distinct ancs ascending,
+    rows_i int32[2B] = the distinct poss and negs ascending, counts int32[2]), all on the device -- for LossSpan.rows:
+    no other row of training_losses2's tables is read by the loss, and no other row gets a gradient from it.
+    out: active_rows_buffers(...) made beforehand (e.g. on another stream than the one this is launched on)."""
+    B = ancs.numel()
+    for v, nm in ((ancs, "ancs"), (poss, "poss"), (negs, "negs")):
+        _index_vec(v, nm, B)
+    dev = ancs.device
+    flags, rows_u, rows_i, counts = active_rows_buffers(B, n_user + n_item, dev) if out is None else out
+    rc = _lib.load().dg_active_rows(ancs.data_ptr(), poss.data_ptr(), negs.data_ptr(), B, int(n_user), int(n_item), flags.data_ptr(),
+                                    rows_u.data_ptr(), rows_i.data_ptr(), counts.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "dg_active_rows")
+    return rows_u, rows_i, counts
 
 
 def diffusion_loss_fwd_spans(spans: Sequence[LossSpan], target, x_start, noise, ts, sqrt_ac, sqrt_1mac, loss_w,
@@ -598,8 +634,11 @@ def wgrad_operand_tables(params: Sequence["DenoiserParams"], n_steps: int) -> No
 
 
 def diffusion_loss_bwd_spans(spans: Sequence[LossSpan], target, x_start, noise, ts, sqrt_ac, sqrt_1mac, loss_w, g_row_loss,
-                             g_out, d_target_add=None, keep_mask=None, drop_seed=None, fused_wgrad: bool = False):
+                             g_out, d_target_add=None, keep_mask=None, drop_seed=None, fused_wgrad: bool = False,
+                             d_x_start_out=None, d_target_out=None):
     """Backward of diffusion_loss_fwd_spans in ONE launch.  d_target_add ([N,64] or None) is added into d_target.
+    Spans with a row list write only those rows of d_x_start / d_target: d_x_start_out / d_target_out are the (zeroed)
+    tables to write into -- d_target_out may be d_target_add itself -- else zeroed tables are made here.
     Returns (d_x_start, d_target, dout_tot, hid, dpre, xn), all [N,64] -- or, with fused_wgrad=True (every span's
     denoiser then has its wg_tab, see wgrad_operand_tables), (d_x_start, d_target, partials): the kernel forms the
     weight gradients' partial sums itself, partials[k] = [ceil(span k rows / 128), partial floats] for
@@ -611,7 +650,15 @@ def diffusion_loss_bwd_spans(spans: Sequence[LossSpan], target, x_start, noise, 
         if t is not None:
             _table(t, nm, n)
     names = ("d_x_start", "d_target") if fused_wgrad else ("d_x_start", "d_target", "dout_tot", "hid", "dpre", "xn")
+    listed = any(sp.rows is not None for sp in spans)
+    if listed and not fused_wgrad:
+        raise DiffGraphHipError("row lists go with fused_wgrad (the operand tables of the other form cover every row)")
     outs = [torch.empty_like(x_start) for _ in names]
+    if listed:
+        for k, given in enumerate((d_x_start_out, d_target_out)):
+            if given is not None:
+                _table(given, names[k] + " table", n)
+            outs[k] = torch.zeros_like(x_start) if given is None else given
     rb = DG_D * 4
     tables = {"target": (target, rb), "x_start": (x_start, rb), "noise": (noise if sqrt_ac is not None else None, rb),
               "ts": (ts, 8), "g_row_loss": (g_row_loss, 8), "g_out": (g_out, rb), "d_target_add": (d_target_add, rb)}
@@ -625,7 +672,8 @@ def diffusion_loss_bwd_spans(spans: Sequence[LossSpan], target, x_start, noise, 
             tab = getattr(sp.dn, "wg_tab", None)
             if tab is None or tuple(tab.shape) != (n_steps, 16):
                 raise DiffGraphHipError("fused_wgrad: the span's denoiser has no operand table (wgrad_operand_tables)")
-            part = torch.empty((-(-sp.n // WG_ROWS_PER_PARTIAL), pf), dtype=torch.float32, device=x_start.device)
+            rows_here = sp.n if sp.rows is None else min(sp.rows.numel(), sp.n)
+            part = torch.empty((-(-rows_here // WG_ROWS_PER_PARTIAL), pf), dtype=torch.float32, device=x_start.device)
             arr[k].wg_tab, arr[k].wg_partials = tab.data_ptr(), part.data_ptr()
             partials.append(part)
     rc = _lib.load().dg_diffusion_loss_bwd_batched(arr, len(spans), n_steps, _ptr(sqrt_ac), _ptr(sqrt_1mac), loss_w.data_ptr(),

@@ -418,6 +418,14 @@ typedef struct dg_loss_task {
    * denoiser's operand table from dg_denoiser_wgrad_tab ([n_steps][16]). */
   const float *wg_tab;
   float *wg_partials;
+  /* rows != NULL: only the table rows rows[0 .. *n_rows) take part (DEVICE int32[rows_cap], ascending; *n_rows a DEVICE
+   * word <= rows_cap <= n; see dg_active_rows).  The forward then writes out / row_loss of those rows only; the backward
+   * writes d_x_start / d_target of those rows only (hand in zeroed tables; d_target may be d_target_add itself) and
+   * takes g_row_loss / g_out as zero elsewhere -- which they are when the loss is only read at listed rows
+   * (diff_loss[batch] and the batch gathers of HGDM.cal_loss, DiffGraph-Rec/Model.py:96-104: a row outside the
+   * batch gets no gradient and its output is never read).  wg_partials: (rows_cap + 127) / 128 partial results. */
+  const int32_t *rows, *n_rows;
+  int32_t rows_cap;
 } dg_loss_task;
 
 /* The random inputs of one training_losses2 call (t.randint(0, steps, (batch,)) and t.randn_like(x_start),
@@ -496,6 +504,14 @@ typedef struct dg_wgrad_reduce_task {
   float *d_w_emb, *d_b_emb, *d_w_in, *d_b_in, *d_w_out, *d_b_out;
 } dg_wgrad_reduce_task;
 int dg_denoiser_wgrad_reduce(const dg_wgrad_reduce_task *tasks, int32_t n_tasks, void *stream);
+
+/* The table rows a batch of HGDM.cal_loss names (DiffGraph-Rec/Model.py:96-104: diff_loss[ancs] / [poss] and the
+ * gathers usrEmbeds[ancs], itmEmbeds[poss], itmEmbeds[negs]): rows_u = the distinct ancs, ascending (DEVICE
+ * int32[n_batch]), rows_i = the distinct poss and negs, ascending (DEVICE int32[2 n_batch]), counts = DEVICE int32[2]
+ * = how many of each.  Indices outside their table are left out.  flags: DEVICE scratch, int32[n_user + n_item].
+ * For dg_loss_task.rows: nothing else of training_losses2's tables is ever read. */
+int dg_active_rows(const int64_t *ancs, const int64_t *poss, const int64_t *negs, int32_t n_batch, int32_t n_user,
+                   int32_t n_item, int32_t *flags, int32_t *rows_u, int32_t *rows_i, int32_t *counts, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * a10: the loss head of HGDM.cal_loss (DiffGraph-Rec/Model.py:101-111; pairPredict,

@@ -350,3 +350,48 @@ def test_nc_coach_run_and_checkpoint(tmp_path):
     assert c.trainEpoch(0) == d.trainEpoch(0)
     for p, q in zip(c.model.parameters(), d.model.parameters()):
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("nu,ni,B", [(40, 60, 64), (31882, 31232, 4096), (1025, 2048, 8192), (5, 3000, 1)])
+def test_active_rows_are_the_distinct_batch_rows_in_order(nu, ni, B):
+    """dg_active_rows: the distinct ancs, and the distinct poss and negs, ascending, with their counts; indices outside
+    their table are left out."""
+    from diffgraph_amd import ops
+    gen = torch.Generator().manual_seed(nu + B)
+    ancs = torch.randint(0, nu, (B,), generator=gen)
+    poss, negs = torch.randint(0, ni, (B,), generator=gen), torch.randint(0, ni, (B,), generator=gen)
+    if B > 8:
+        ancs[3], poss[5], negs[7] = -1, ni, 2 ** 40
+    rows_u, rows_i, counts = ops.active_rows(ancs.to(DEV), poss.to(DEV), negs.to(DEV), nu, ni)
+    cu, ci = (int(c) for c in counts.cpu())
+    want_u = torch.unique(ancs[(ancs >= 0) & (ancs < nu)])
+    both = torch.cat([poss, negs])
+    want_i = torch.unique(both[(both >= 0) & (both < ni)])
+    assert cu == want_u.numel() and ci == want_i.numel()
+    assert torch.equal(rows_u[:cu].cpu().long(), want_u) and torch.equal(rows_i[:ci].cpu().long(), want_i)
+
+
+def test_loss_on_the_batch_rows_equals_the_loss_over_every_row():
+    """HGDM.cal_loss with the denoisers run over the rows the batch names only (the default) against the same call over
+    every row, as the reference runs it (loss_on_batch_rows = False): the same four values bit for bit, the same
+    gradient of the table bit for bit, the denoisers' weight gradients to the last bits (their row sums are grouped
+    differently)."""
+    h = _handler()
+    torch.manual_seed(11)
+    m = dg.rec.HGDM(h, _args(64), device=DEV).eval()
+    nu, ni = h.userNum, h.itemNum
+    gen = torch.Generator().manual_seed(2)
+    ancs, poss, negs = (torch.randint(0, hi, (64,), generator=gen).to(DEV) for hi in (nu, ni, ni))
+    ts = torch.randint(0, 200, (nu + ni,), generator=gen).to(DEV)
+    noise = torch.randn(nu + ni, 64, generator=gen).to(DEV)
+    got = {}
+    for listed in (True, False):
+        m.loss_on_batch_rows = listed
+        m.zero_grad()
+        res = m.cal_loss_vector(ancs, poss, negs, ts[:nu], noise[:nu], ts[nu:], noise[nu:])
+        res.backward(torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=DEV))
+        got[listed] = (res.detach().clone(), m.embedding_table.grad.clone(),
+                       [p.grad.clone() for p in m.usr_denoiser.parameters()] + [p.grad.clone() for p in m.item_denoiser.parameters()])
+    assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
+    for a, b in zip(got[True][2], got[False][2]):
+        assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(b.abs().max()))
