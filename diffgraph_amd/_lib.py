@@ -110,7 +110,7 @@ SIGNATURES = {
     "dg_graphset_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "dg_set_layer_first": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p]),
     "dg_set_layer_last": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int32, C.c_void_p]),
-    "dg_set_layer_bwd_top": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int32, C.c_void_p]),
+    "dg_set_layer_bwd_top": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int32, C.c_void_p]),
     "dg_set_layer_bwd_mid": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_int32, C.c_void_p]),
     "dg_set_layer_bwd_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dg_set_layer_bwd_last_adam": (C.c_int, [C.c_void_p] * 8 + [C.c_float] * 5 + [C.c_int32, C.c_void_p]),

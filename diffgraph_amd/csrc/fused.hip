@@ -69,6 +69,7 @@ struct set_dev {
   const float *e_saved;  // backward: the layer's forward activations, stacked
   const float *d_first, *d_rest;  // backward: gradients wrt the two sums
   int32_t n, n_graphs, n_hub, n_seg_slots, n_gseg_slots, n_rec;
+  const int32_t *row_flags;   // set_rowwise_kernel: rows whose flag is 0 have zero gradients coming in (or NULL)
   float slope;
   // M_BWD_LAST_ADAM: the table the gradient belongs to, its Adam moments and state {steps taken, ..}
   float *adam_p, *adam_m, *adam_v;
@@ -354,6 +355,13 @@ __global__ __launch_bounds__(256) void set_rowwise_kernel(const set_dev T) {
   const int l = threadIdx.x & 15;
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (row >= T.n) return;
+  if (T.row_flags != nullptr && T.row_flags[row] == 0) {
+    // no gradient reaches this row's layer sums: dZ is zero whatever the row holds -- written without reading it
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const size_t o = (size_t)row * (DG_D / 4) + l, gs = (size_t)T.n * (DG_D / 4);
+    for (int g = 0; g < T.n_graphs; ++g) store_stream(T.e_out, g * gs + o, z);
+    return;
+  }
   set_ctx c;
   load_set_ctx<M_BWD_TOP>(T, row, l, c);
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -389,6 +397,7 @@ int fill(const dg_graphset *s, int mode, set_dev &t) {
   t.n = s->n; t.n_graphs = s->n_graphs; t.n_hub = s->n_hub; t.n_seg_slots = s->n_seg_slots; t.n_gseg_slots = s->n_gseg_slots;
   t.n_rec = s->n_rec;
   t.slope = 0.f;
+  t.row_flags = nullptr;
   t.adam_p = t.adam_m = t.adam_v = nullptr; t.adam_state = nullptr;
   t.lr = t.beta1 = t.beta2 = t.eps = t.weight_decay = 0.f;
   int device = 0;
@@ -687,13 +696,13 @@ extern "C" int dg_set_layer_last(dg_graphset *set, const float *x, const float *
 }
 
 extern "C" int dg_set_layer_bwd_top(dg_graphset *set, const float *e_saved, const float *d_first, const float *d_rest,
-                                    float *w_out, float slope, int32_t d, void *stream) {
+                                    float *w_out, const int32_t *row_flags, float slope, int32_t d, void *stream) {
   int rc = check_d("dg_set_layer_bwd_top", set, d);
   if (rc) return rc;
   if (!e_saved || !d_first || !d_rest || !w_out) return dg_fail(DG_ERR_ARG, "dg_set_layer_bwd_top: NULL argument");
   set_dev t;
   if ((rc = fill(set, M_BWD_TOP, t))) return rc;
-  t.e_saved = e_saved; t.d_first = d_first; t.d_rest = d_rest; t.e_out = w_out; t.slope = slope;
+  t.e_saved = e_saved; t.d_first = d_first; t.d_rest = d_rest; t.e_out = w_out; t.slope = slope; t.row_flags = row_flags;
   hipLaunchKernelGGL(set_rowwise_kernel, dim3((set->n + 15) >> 4), dim3(256), 0, (hipStream_t)stream, t);
   DG_HIP(hipGetLastError());
   return 0;

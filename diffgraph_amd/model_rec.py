@@ -69,6 +69,8 @@ class _PropagateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_ui, d_het):
         model, saved = ctx.model, ctx.saved
+        # (a loss that reaches the layer sums at the batch's rows only -- _RecLossFn -- has said which: elsewhere dZ_2 is zero)
+        flags, model._bwd_row_flags = getattr(model, "_bwd_row_flags", None), None
         graphs = [model.target_adj] + model.behavior_mats
         slope, L = float(model.act.negative_slope), model.n_layers
         ref = saved[0][0]
@@ -86,7 +88,7 @@ class _PropagateFn(torch.autograd.Function):
                                    "(the graph-set path overwrites them; run the forward again)")
             e1, e2 = ctx.stacked
             ctx.stacked = None
-            ops.set_layer_bwd_top(ctx.gset, e2, d_ui, d_het, e2, slope)
+            ops.set_layer_bwd_top(ctx.gset, e2, d_ui, d_het, e2, slope, row_flags=flags)
             ops.set_layer_bwd_mid(ctx.gset, e2, e1, d_ui, d_het, e1, slope)
             stack = e1
             w = [stack[g] for g in range(len(graphs))]
@@ -215,6 +217,8 @@ class _RecLossFn(torch.autograd.Function):
         else:
             res = ops.denoiser_wgrad_reduce(jobs)               # both denoisers, one set of launches
         grads = [g for r in res for g in r]
+        # d ui and d het are zero outside the listed rows (ui and het have no other reader: cal_loss_vector made them)
+        model._bwd_row_flags = None if act is None else act[0]
         return (d_ui, d_het, None, None, None, None, None, None, None, None) + tuple(grads)
 
 

@@ -253,15 +253,18 @@ def set_layer_last(gset: GraphSet, x: torch.Tensor, e0: torch.Tensor, sum_first:
 
 
 def set_layer_bwd_top(gset: GraphSet, e_saved: torch.Tensor, d_first: torch.Tensor, d_rest: torch.Tensor,
-                      w_out: torch.Tensor, slope: float = 0.5) -> None:
-    """Backward through the last layer's LeakyReLU / normalize / layer sum for every graph of the set (no gather)."""
+                      w_out: torch.Tensor, slope: float = 0.5, row_flags: Optional[torch.Tensor] = None) -> None:
+    """Backward through the last layer's LeakyReLU / normalize / layer sum for every graph of the set (no gather).
+    row_flags (int32 [nodes]): 0 where the rows of d_first and d_rest are zero -- those rows of w_out become zeros unread."""
     n = gset.num_nodes()
+    if row_flags is not None:
+        _vec(row_flags, "row_flags", torch.int32, n)
     _stacked(e_saved, "e_saved", gset)
     _stacked(w_out, "w_out", gset)
     _table(d_first, "d_first", n)
     _table(d_rest, "d_rest", n)
     rc = _lib.load().dg_set_layer_bwd_top(gset.handle, e_saved.data_ptr(), d_first.data_ptr(), d_rest.data_ptr(),
-                                          w_out.data_ptr(), float(slope), DG_D, _lib.stream_ptr(w_out.device))
+                                          w_out.data_ptr(), _ptr(row_flags), float(slope), DG_D, _lib.stream_ptr(w_out.device))
     _lib.check(rc, "dg_set_layer_bwd_top")
 
 

@@ -272,8 +272,10 @@ int dg_graphset_counts(const dg_graphset *set, int32_t *counts_host);
 int dg_set_layer_first(dg_graphset *set, const float *x, float *e_out, float slope, int32_t d, void *stream);
 int dg_set_layer_last(dg_graphset *set, const float *x, const float *e0, float *sum_first, float *sum_rest,
                       float *e_out, float slope, int32_t d, void *stream);
+/* row_flags (nullable; DEVICE int32[nodes], e.g. the flags of dg_active_rows): rows whose flag is 0 have zero rows in
+ * d_first and d_rest -- their rows of w_out are written as zeros without reading anything else. */
 int dg_set_layer_bwd_top(dg_graphset *set, const float *e_saved, const float *d_first, const float *d_rest,
-                         float *w_out, float slope, int32_t d, void *stream);
+                         float *w_out, const int32_t *row_flags, float slope, int32_t d, void *stream);
 int dg_set_layer_bwd_mid(dg_graphset *set, const float *w_in, const float *e_saved, const float *d_first,
                          const float *d_rest, float *w_out, float slope, int32_t d, void *stream);
 int dg_set_layer_bwd_last(dg_graphset *set, const float *w_in, float *g_out, int32_t d, void *stream);
