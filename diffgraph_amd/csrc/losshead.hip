@@ -273,21 +273,24 @@ __global__ __launch_bounds__(256) void mark_rows_kernel(const int64_t *__restric
 }
 
 // The flagged rows of the user table and of the item table, each as an ascending list of row numbers inside its table
-// and a count.  A workgroup takes 1024 consecutive flags of one table (one per thread): it first counts the flags set
-// before its run -- every workgroup on its own, a few coalesced reads per thread instead of a scan across workgroups --
-// then numbers its own by ballots and writes them behind.  The table's last workgroup also writes the count.
-__global__ __launch_bounds__(1024) void compact_rows_kernel(const int *__restrict__ flags, int n_user, int n_item, int blocks_u,
-                                                            int *__restrict__ rows_u, int cap_u, int *__restrict__ rows_i,
-                                                            int cap_i, int *__restrict__ counts) {
-  __shared__ int wave_sum[16], before_sum[16];
+// and a count.  A workgroup takes kCompact consecutive flags of one table (one per thread): it first counts the flags
+// set before its run -- every workgroup on its own, a few coalesced reads per thread instead of a scan across
+// workgroups -- then numbers its own by ballots and writes them behind.  The table's last workgroup also writes the
+// count.  (Small workgroups: the launch runs beside a propagation launch that fills the chip, and finds room sooner.)
+constexpr int kCompact = 256;
+__global__ __launch_bounds__(kCompact) void compact_rows_kernel(const int *__restrict__ flags, int n_user, int n_item, int blocks_u,
+                                                                int *__restrict__ rows_u, int cap_u, int *__restrict__ rows_i,
+                                                                int cap_i, int *__restrict__ counts) {
+  constexpr int kWaves = kCompact / 64;
+  __shared__ int wave_sum[kWaves], before_sum[kWaves];
   const bool items = (int)blockIdx.x >= blocks_u;
   const int *f = flags + (items ? n_user : 0);
   const int len = items ? n_item : n_user, cap = items ? cap_i : cap_u;
   int *rows = items ? rows_i : rows_u;
-  const int chunk0 = ((int)blockIdx.x - (items ? blocks_u : 0)) * 1024;
+  const int chunk0 = ((int)blockIdx.x - (items ? blocks_u : 0)) * kCompact;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int before = 0;
-  for (int r = threadIdx.x; r < chunk0; r += 1024) before += f[r] != 0;
+  for (int r = threadIdx.x; r < chunk0; r += kCompact) before += f[r] != 0;
   for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
   const int r = chunk0 + (int)threadIdx.x;
   const bool mine = r < len && f[r] != 0;
@@ -295,14 +298,14 @@ __global__ __launch_bounds__(1024) void compact_rows_kernel(const int *__restric
   if (lane == 0) { before_sum[wave] = before; wave_sum[wave] = __popcll(bal); }
   __syncthreads();
   int at = 0, total = 0;
-  for (int w = 0; w < 16; ++w) {
+  for (int w = 0; w < kWaves; ++w) {
     at += before_sum[w];
     if (w < wave) at += wave_sum[w];
     total += before_sum[w] + wave_sum[w];
   }
   at += __popcll(bal & ((1ull << lane) - 1ull));
   if (mine && at < cap) rows[at] = r;
-  if (threadIdx.x == 0 && chunk0 + 1024 >= len) counts[items ? 1 : 0] = min(total, cap);
+  if (threadIdx.x == 0 && chunk0 + kCompact >= len) counts[items ? 1 : 0] = min(total, cap);
 }
 
 }  // namespace
@@ -315,8 +318,8 @@ extern "C" int dg_active_rows(const int64_t *ancs, const int64_t *poss, const in
   DG_HIP(hipMemsetAsync(flags, 0, ((size_t)n_user + (size_t)n_item) * sizeof(int32_t), (hipStream_t)stream));
   hipLaunchKernelGGL(mark_rows_kernel, dim3((3 * n_batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, ancs, poss, negs, n_batch,
                      n_user, n_item, flags);
-  const int blocks_u = (n_user + 1023) / 1024, blocks_i = (n_item + 1023) / 1024;
-  hipLaunchKernelGGL(compact_rows_kernel, dim3(blocks_u + blocks_i), dim3(1024), 0, (hipStream_t)stream, flags, n_user, n_item, blocks_u,
+  const int blocks_u = (n_user + kCompact - 1) / kCompact, blocks_i = (n_item + kCompact - 1) / kCompact;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(blocks_u + blocks_i), dim3(kCompact), 0, (hipStream_t)stream, flags, n_user, n_item, blocks_u,
                      rows_u, n_batch, rows_i, 2 * n_batch, counts);
   DG_HIP(hipGetLastError());
   return 0;
