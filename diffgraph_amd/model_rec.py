@@ -69,8 +69,9 @@ class _PropagateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_ui, d_het):
         model, saved = ctx.model, ctx.saved
-        # (a loss that reaches the layer sums at the batch's rows only -- _RecLossFn -- has said which: elsewhere dZ_2 is zero)
-        flags, model._bwd_row_flags = getattr(model, "_bwd_row_flags", None), None
+        # (cal_loss_vector, whose loss reaches these layer sums at the batch's rows only, has said which on this very
+        # node: elsewhere the incoming gradients, and with them dZ_2, are zero)
+        flags = getattr(ctx, "row_flags", None)
         graphs = [model.target_adj] + model.behavior_mats
         slope, L = float(model.act.negative_slope), model.n_layers
         ref = saved[0][0]
@@ -217,8 +218,6 @@ class _RecLossFn(torch.autograd.Function):
         else:
             res = ops.denoiser_wgrad_reduce(jobs)               # both denoisers, one set of launches
         grads = [g for r in res for g in r]
-        # d ui and d het are zero outside the listed rows (ui and het have no other reader: cal_loss_vector made them)
-        model._bwd_row_flags = None if act is None else act[0]
         return (d_ui, d_het, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
@@ -537,6 +536,10 @@ class HGDM(nn.Module):
                     ops.clear_table(self._dhet_buf)
         self.join_side_work()
         self._active = act
+        if act is not None and ui.grad_fn is not None:
+            # ui and het have no reader but the loss below, which touches them at the batch's rows only: the backward
+            # pass of THIS propagation may take every other row's incoming gradient as zero
+            ui.grad_fn.row_flags = act[0]
         drop = dropout_args(denoisers, keep, dev, self.draw_state[2:3])
         weights = []
         for dn in (self.usr_denoiser, self.item_denoiser):
