@@ -23,7 +23,6 @@ Differences a caller can see:
 from __future__ import annotations
 
 import math
-from typing import Optional
 
 import numpy as np
 import torch

@@ -19,7 +19,6 @@ CPU with torch.distributed's gloo backend; the product backend is HipBackend (HI
 """
 from __future__ import annotations
 
-import json
 import os
 import sys
 import time

@@ -8,7 +8,7 @@ computes Recall@k / NDCG@k without the score matrix ever existing in memory.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+from typing import Dict, List
 
 import numpy as np
 import torch

@@ -8,7 +8,7 @@ device-side CSR + degree norms + row schedule created by dg_graph_create.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 

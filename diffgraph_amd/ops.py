@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import DG_D, DG_IN_PRESCALED, DG_OUT_NORM, DG_OUT_PRESCALE, DiffGraphHipError
+from ._lib import DG_D, DiffGraphHipError
 from .graph import CSRGraph, GraphSet
 
 
